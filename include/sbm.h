@@ -1,0 +1,205 @@
+/*
+ * sbm.h -- C ABI of libsbm_hip.so, the MI355X (gfx950) implementation of the
+ * parameter-fitting inner loop of FedericoV/SysBio_Modeling.
+ *
+ * Every entry point replaces one Python-level interface of the reference; the
+ * reference has no FFI of its own (pure Python 2 + SciPy), so the "binding a
+ * maintainer would add" is a ctypes stub -- see INTEGRATION.md.  Citations are
+ * relative to the reference tree.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs; no C++ or torch types.
+ *   - every function returns 0 on success, <0 on error; sbm_last_error() gives
+ *     the message (thread-local).  No exception crosses this boundary.
+ *   - the caller owns every buffer.  "_dev" arguments are device pointers valid
+ *     on the context's device; the library borrows them for the call only.
+ *     Calls are enqueued on the context's stream and return without waiting
+ *     (call sbm_ctx_synchronize); the *_host variants take host pointers, stage
+ *     through library scratch and return when the results are in host memory.
+ *   - all reals are float64, row-major; statuses / counters are int32.
+ *   - one context per device per thread of use; contexts are independent.
+ */
+#ifndef SBM_H
+#define SBM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBM_ABI_VERSION 1
+
+typedef struct sbm_ctx sbm_ctx;
+typedef struct sbm_model sbm_model;
+typedef struct sbm_project sbm_project;
+
+/* integrators.  The reference always uses LSODA at rtol = atol = 1e-10
+ * (model/ode_model.py:122-123,167-168); these are the GPU replacements. */
+enum {
+  SBM_RK4_FIXED = 0, /* classic RK4, fixed step h0 between output times        */
+  SBM_DOPRI45 = 1    /* Dormand-Prince 5(4), error control on state AND sens.   */
+};
+
+typedef struct sbm_integrator_opts {
+  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45                              */
+  int32_t max_steps; /* per trajectory, accepted + rejected; <=0 -> 1000000      */
+  double rtol;       /* DOPRI45 relative tolerance                               */
+  double atol;       /* DOPRI45 absolute tolerance                               */
+  double h0;         /* RK4: step size; DOPRI45: initial step (<=0 -> automatic) */
+} sbm_integrator_opts;
+
+/* per-trajectory status written next to the results (the reference does not
+ * check LSODA failures, model/ode_model.py:122,167; non-zero statuses are what
+ * the host maps to the reference's inf rows, squared_loss_function.py:28-32) */
+enum {
+  SBM_OK = 0,
+  SBM_MAX_STEPS = 1,
+  SBM_NON_FINITE = 2,
+  SBM_STEP_UNDERFLOW = 3
+};
+
+/* ---- context ----------------------------------------------------------- */
+/* stream: the hipStream_t every call of this context enqueues on (e.g. torch's
+ * current stream); NULL = the device's default stream. */
+int sbm_ctx_create(int device, void* stream, sbm_ctx** out);
+int sbm_ctx_destroy(sbm_ctx* ctx);
+int sbm_ctx_synchronize(sbm_ctx* ctx);
+int sbm_ctx_device(const sbm_ctx* ctx);
+const char* sbm_last_error(void);
+int sbm_abi_version(void);
+
+/* ---- model: replaces OdeModel.__init__ (model/ode_model.py:27-44) ------- */
+/* plugin_path: shared object built from a generated model header
+ * (sysbio_modeling_amd/symbolic/emit.py + csrc/sbm_plugin_main.hip); it holds
+ * the integrator kernels specialised for that model's RHS / sensitivity RHS. */
+int sbm_model_load(sbm_ctx* ctx, const char* plugin_path, sbm_model** out);
+int sbm_model_unload(sbm_model* m);
+/* n_vars = OdeModel.n_vars (model/abstract_model.py:18-21); n_params =
+ * len(param_order); n_sens = number of non-fixed parameters. */
+int sbm_model_info(const sbm_model* m, int32_t* n_vars, int32_t* n_params, int32_t* n_sens,
+                   char* name_buf, int32_t name_buf_len);
+
+/* ---- OdeModel.simulate (model/ode_model.py:128-169), batched ------------ */
+/* P      [V][n_params]            one parameter vector per trajectory
+ * t_out  [n_t]                    non-decreasing output times, t_out[0] >= 0;
+ *                                 integration starts at t = 0
+ * y0     [n_vars] or NULL         initial state (NULL -> zeros, as the
+ *                                 reference's default, ode_model.py:151-152)
+ * Y      [V][n_t][n_vars]         out
+ * status [V], n_steps [V] (accepted steps), n_reject [V]: out, each nullable */
+int sbm_simulate_batch(sbm_model* m, const double* P_dev, int32_t V, const double* t_out_dev,
+                       int32_t n_t, const double* y0_dev, const sbm_integrator_opts* opts,
+                       double* Y_dev, int32_t* status_dev, int32_t* n_steps_dev,
+                       int32_t* n_reject_dev);
+int sbm_simulate_batch_host(sbm_model* m, const double* P, int32_t V, const double* t_out,
+                            int32_t n_t, const double* y0, const sbm_integrator_opts* opts,
+                            double* Y, int32_t* status, int32_t* n_steps, int32_t* n_reject);
+
+/* ---- OdeModel.calc_jacobian (model/ode_model.py:83-126), batched -------- */
+/* Integrates the augmented system [y; S], S' = J_y S + J_p.
+ * yS0 [n_vars + n_vars*n_sens] or NULL (-> zeros): the reference's
+ *      init_conditions argument, state first then S, state-major/param-minor.
+ * Y   [V][n_t][n_vars]           out, nullable (the reference discards it, :125)
+ * S   [V][n_t][n_vars][n_sens]   out; S[..., i, j] = d y_i / d p_j, i.e. the
+ *      reference's column i*k + j of calc_jacobian's return value */
+int sbm_sens_batch(sbm_model* m, const double* P_dev, int32_t V, const double* t_out_dev,
+                   int32_t n_t, const double* yS0_dev, const sbm_integrator_opts* opts,
+                   double* Y_dev, double* S_dev, int32_t* status_dev, int32_t* n_steps_dev,
+                   int32_t* n_reject_dev);
+int sbm_sens_batch_host(sbm_model* m, const double* P, int32_t V, const double* t_out,
+                        int32_t n_t, const double* yS0, const sbm_integrator_opts* opts,
+                        double* Y, double* S, int32_t* status, int32_t* n_steps,
+                        int32_t* n_reject);
+
+/* ---- Project (project/base_project.py) ---------------------------------- */
+/* Flattened, immutable description of a Project: what _set_local_param_idx
+ * (:164-276), _measurements_as_dataframe (:296-341) and _make_mapping (:109-136)
+ * build, as index arrays.  All arrays are HOST pointers, copied at load. */
+typedef struct sbm_project_desc {
+  int32_t n_experiments;     /* E, in the reference's sorted-by-name order (:624) */
+  int32_t n_project_params;  /* q = Project.n_project_params                      */
+  int32_t n_rows;            /* R = measurement rows (t = 0 rows already dropped) */
+  int32_t n_sf_groups;       /* scale-factor groups; 0 = loss without SF          */
+  int32_t n_prior_rows;      /* parameter-prior rows appended after the R rows    */
+  int32_t n_sf_prior_rows;   /* scale-factor-prior rows appended after those      */
+
+  /* theta -> p gather, get_experiment_parameters (:343-363):
+   * p[e][m] = exp(theta[pmap[e][m]]) if pmap >= 0 else pfixed[e][m] */
+  const int32_t* pmap;   /* [E][n_params] */
+  const double* pfixed;  /* [E][n_params] */
+  /* model param m -> sensitivity column (or -1 when fixed at code generation) */
+  const int32_t* sens_col; /* [n_params] */
+
+  /* per-experiment output grid: the entries of linspace(0, t_end, 1000) picked by
+   * searchsorted (project/utils.py:18-21), unique and increasing */
+  const int32_t* tgrid_off; /* [E+1] offsets into tgrid */
+  const double* tgrid;      /* [tgrid_off[E]] */
+
+  /* rows, in the reference's row order (experiment name, measurement name, time) */
+  const int32_t* row_exp;     /* [R] experiment index                              */
+  const int32_t* row_tidx;    /* [R] index into that experiment's tgrid            */
+  const int32_t* row_var_off; /* [R+1] offsets into row_vars ('direct': 1 entry,   */
+  const int32_t* row_vars;    /*      'sum': several; project/utils.py:10-89)      */
+  const double* row_data;     /* [R] measurement mean                              */
+  const double* row_sigma;    /* [R] measurement std (never 0,                     */
+                              /*     measurement/abstract_measurement.py:15-16)    */
+  const int32_t* row_sf;      /* [R] scale-factor group or -1                      */
+
+  /* parameter log-priors (:316-325, :427-437): residual (theta[idx]-mean)/sigma */
+  const int32_t* prior_idx;  /* [n_prior_rows] */
+  const double* prior_mean;  /* [n_prior_rows] */
+  const double* prior_sigma; /* [n_prior_rows] */
+
+  /* scale-factor log-priors ("~~SF_Prior" rows, :327-335): residual
+   * (log B_g - mean)/sigma, Jacobian row (dB_g/dtheta)/B_g
+   * (linear_scale_factor.py:44-61, abstract_loss_function.py:93-120) */
+  const int32_t* sf_prior_group; /* [n_sf_prior_rows] */
+  const double* sf_prior_mean;   /* [n_sf_prior_rows] */
+  const double* sf_prior_sigma;  /* [n_sf_prior_rows] */
+
+  /* reference_compat != 0 reproduces two reference behaviours exactly:
+   * the Jacobian is NOT divided by sigma (squared_loss_function.py:52-53,76)
+   * and prior rows of J stay zero (base_project.py:519-530 is never called).
+   * 0 gives d r / d theta (J/sigma, prior rows 1/sigma_prior). */
+  int32_t reference_compat;
+} sbm_project_desc;
+
+int sbm_project_load(sbm_model* m, const sbm_project_desc* desc, sbm_project** out);
+int sbm_project_unload(sbm_project* p);
+
+/* Project.residuals (:708-729) for V parameter vectors at once.
+ * Theta   [V][q]          log-space project vectors
+ * sims    [V][R]          out, nullable: unscaled simulated values per row
+ *                         (the 'mean' column of _simulations_df, :387-389)
+ * R_out   [V][R+n_prior+n_sf_prior]  out: (B*sim - data)/sigma  (squared_loss_function.py:40)
+ * sf      [V][n_sf]       out, nullable: scale factors B (linear_scale_factor.py:27-31)
+ * norms   [V]             out, nullable: sum of squared residuals (2 * RSS)
+ * status  [V]             out, nullable: max status over the vector's trajectories;
+ *                         rows of a failed vector are +inf as in the reference */
+int sbm_residuals_batch(sbm_project* p, const double* Theta_dev, int32_t V,
+                        const sbm_integrator_opts* opts, double* sims_dev, double* R_dev,
+                        double* sf_dev, double* norms_dev, int32_t* status_dev,
+                        int32_t* n_steps_dev);
+
+/* Project.calc_project_jacobian (:731-771): one augmented integration gives both.
+ * J_out   [V][R+n_prior+n_sf_prior][q]   out: B*J + sim (x) dB/dtheta
+ *                             (squared_loss_function.py:44-80, linear_scale_factor.py:33-42)
+ * Jmodel  [V][R][q]           out, nullable: d sim / d theta before scale factors
+ *                             (_model_jacobian_df, base_project.py:482-485)
+ * sf_grad [V][n_sf][q]        out, nullable: dB/dtheta (linear_scale_factor.py:33-42)
+ * grad    [V][q]              out, nullable: J^T r (calc_rss_gradient, :803-805) */
+int sbm_jacobian_batch(sbm_project* p, const double* Theta_dev, int32_t V,
+                       const sbm_integrator_opts* opts, double* sims_dev, double* R_dev,
+                       double* J_dev, double* Jmodel_dev, double* sf_dev, double* sf_grad_dev,
+                       double* norms_dev, double* grad_dev, int32_t* status_dev,
+                       int32_t* n_steps_dev);
+
+/* bytes of device scratch the project keeps for V vectors (allocated lazily,
+ * grown on demand, freed at unload) */
+int64_t sbm_project_scratch_bytes(const sbm_project* p, int32_t V, int32_t with_sens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBM_H */

@@ -1,0 +1,114 @@
+"""ORACLE (test infrastructure, not product code) -- integration half of the hot path.
+
+CPU restatement of the reference's ``OdeModel.simulate`` (model/ode_model.py:128-169)
+and ``OdeModel.calc_jacobian`` (model/ode_model.py:83-126).  The reference's
+algorithm on this path lives in a third-party dependency that is not under
+/root/reference: ``scipy.integrate.odeint`` -> ODEPACK LSODA (Fortran).  The
+reference pins no SciPy version (no setup.py / requirements); this container
+and the GPU box both carry SciPy 1.15.3.  The restatement therefore issues the
+reference's exact call
+
+    odeint(func_wrapper, init_conditions, t_sim, Dfun=None, col_deriv=True,
+           rtol=1e-10, atol=1e-10)                      (ode_model.py:122-123,167-168)
+
+on a right-hand side with the reference callback contract f(y, t, yout, p).
+
+PINNED: tests/test_oracle_golden.py checks this module against
+  * the reference's own golden array (tests/test_OdeModel.py:25-26) and analytic
+    sensitivities (:42-45),
+  * tests/golden/*.npz, produced by importing the REAL reference ``OdeModel``
+    (tests/golden/make_golden.py, run in the build container).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+from scipy.integrate import odeint
+
+RTOL = 1e-10  # model/ode_model.py:123,168
+ATOL = 1e-10
+
+
+def _wrap(fn, n_out, params):
+    """func_wrapper of the reference (ode_model.py:109-112,162-165): closure-local yout."""
+    yout = np.zeros(n_out)
+    p = np.ascontiguousarray(params, dtype=np.float64)
+
+    def func_wrapper(y, t):
+        fn(y, t, yout, p)
+        return yout
+    return func_wrapper
+
+
+def _wrap_c(cfn, n_out, params):
+    """Same wrapper around a compiled C RHS (the role numba plays in the reference,
+    ode_model.py:50-51): identical arithmetic to the generated Python callable."""
+    yout = np.zeros(n_out)
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    yout_p = yout.ctypes.data_as(dp)
+    p_p = p.ctypes.data_as(dp)
+
+    def func_wrapper(y, t):
+        yc = np.ascontiguousarray(y, dtype=np.float64)
+        cfn(yc.ctypes.data_as(dp), float(t), yout_p, p_p)
+        return yout
+    func_wrapper._keep = (yout, p)
+    return func_wrapper
+
+
+def simulate(model, experiment_params, t_sim, init_conditions=None, n_vars=None, full_output=False,
+             use_c=False):
+    """ode_model.py:128-169.  ``model``: callable f(y,t,yout,p) or a GeneratedModel."""
+    gm = None if callable(model) else model
+    if gm is not None:
+        n_vars = gm.n_vars
+    if init_conditions is None:
+        init_conditions = np.zeros((n_vars,))                       # :151-152
+    if gm is not None and use_c:
+        fw = _wrap_c(gm.c_library().sbm_rhs, len(init_conditions), experiment_params)
+    else:
+        fw = _wrap(gm.model if gm is not None else model, len(init_conditions), experiment_params)
+    return odeint(fw, init_conditions, t_sim, Dfun=None, col_deriv=True, rtol=RTOL, atol=ATOL,
+                  full_output=full_output)
+
+
+def calc_jacobian(sens_model, experiment_params, t_sim, init_conditions=None, n_vars=None, n_sens=None,
+                  full_output=False, use_c=False, return_states=False):
+    """ode_model.py:83-126: integrate [y; S], return the S part ``sim[:, n_vars:]``."""
+    gm = None if callable(sens_model) else sens_model
+    if gm is not None:
+        n_vars, n_sens = gm.n_vars, gm.n_sens
+    if init_conditions is None:
+        init_conditions = np.zeros((n_vars + n_vars * n_sens,))     # base_project.py:512
+    if gm is not None and use_c:
+        fw = _wrap_c(gm.c_library().sbm_sens_rhs, len(init_conditions), experiment_params)
+    else:
+        fw = _wrap(gm.sens_model if gm is not None else sens_model, len(init_conditions), experiment_params)
+    out = odeint(fw, init_conditions, t_sim, Dfun=None, col_deriv=True, rtol=RTOL, atol=ATOL,
+                 full_output=full_output)
+    sim, info = (out if full_output else (out, None))
+    sens = sim[:, n_vars:]                                          # :125
+    res = (sens, sim[:, :n_vars]) if return_states else sens
+    return (res, info) if full_output else res
+
+
+def tight_solution(gm, experiment_params, t_sim, sens=True):
+    """Independent high-accuracy solution (DOP853, rtol 1e-13) used to tell
+    'GPU more accurate than LSODA' from 'GPU wrong' (SURVEY.md section 8(d))."""
+    from scipy.integrate import solve_ivp
+    n, k = gm.n_vars, gm.n_sens
+    N = n + n * k if sens else n
+    p = np.ascontiguousarray(experiment_params, dtype=np.float64)
+    yout = np.zeros(N)
+    fn = gm.sens_model if sens else gm.model
+
+    def f(t, y):
+        fn(y, t, yout, p)
+        return yout.copy()
+    sol = solve_ivp(f, (0.0, float(t_sim[-1])), np.zeros(N), method='DOP853', t_eval=np.asarray(t_sim),
+                    rtol=1e-13, atol=1e-16)
+    return sol.y.T

@@ -1,0 +1,244 @@
+"""ctypes binding of libsbm_hip.so (include/sbm.h).  No fallbacks: if the library
+is missing or a call fails this raises -- there is no CPU path in the product."""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from . import build
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+SBM_RK4_FIXED = 0
+SBM_DOPRI45 = 1
+STATUS_NAMES = {0: 'ok', 1: 'max_steps', 2: 'non_finite', 3: 'step_underflow'}
+
+
+class SbmError(RuntimeError):
+    pass
+
+
+class IntegratorOpts(ctypes.Structure):
+    _fields_ = [('method', ctypes.c_int32), ('max_steps', ctypes.c_int32),
+                ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double)]
+
+
+class ProjectDesc(ctypes.Structure):
+    _fields_ = [
+        ('n_experiments', ctypes.c_int32), ('n_project_params', ctypes.c_int32), ('n_rows', ctypes.c_int32),
+        ('n_sf_groups', ctypes.c_int32), ('n_prior_rows', ctypes.c_int32), ('n_sf_prior_rows', ctypes.c_int32),
+        ('pmap', c_int32_p), ('pfixed', c_double_p), ('sens_col', c_int32_p),
+        ('tgrid_off', c_int32_p), ('tgrid', c_double_p),
+        ('row_exp', c_int32_p), ('row_tidx', c_int32_p), ('row_var_off', c_int32_p), ('row_vars', c_int32_p),
+        ('row_data', c_double_p), ('row_sigma', c_double_p), ('row_sf', c_int32_p),
+        ('prior_idx', c_int32_p), ('prior_mean', c_double_p), ('prior_sigma', c_double_p),
+        ('sf_prior_group', c_int32_p), ('sf_prior_mean', c_double_p), ('sf_prior_sigma', c_double_p),
+        ('reference_compat', ctypes.c_int32),
+    ]
+
+
+# every symbol include/sbm.h declares: (restype, argtypes)
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_opts_p = ctypes.POINTER(IntegratorOpts)
+SIGNATURES = {
+    'sbm_ctx_create': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.POINTER(_vp)]),
+    'sbm_ctx_destroy': (ctypes.c_int, [_vp]),
+    'sbm_ctx_synchronize': (ctypes.c_int, [_vp]),
+    'sbm_ctx_device': (ctypes.c_int, [_vp]),
+    'sbm_last_error': (ctypes.c_char_p, []),
+    'sbm_abi_version': (ctypes.c_int, []),
+    'sbm_model_load': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    'sbm_model_unload': (ctypes.c_int, [_vp]),
+    'sbm_model_info': (ctypes.c_int, [_vp, c_int32_p, c_int32_p, c_int32_p, ctypes.c_char_p, _i32]),
+    'sbm_simulate_batch': (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _opts_p, _vp, _vp, _vp, _vp]),
+    'sbm_simulate_batch_host': (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _opts_p, _vp, _vp, _vp, _vp]),
+    'sbm_sens_batch': (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _opts_p, _vp, _vp, _vp, _vp, _vp]),
+    'sbm_sens_batch_host': (ctypes.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _opts_p, _vp, _vp, _vp, _vp, _vp]),
+    'sbm_project_load': (ctypes.c_int, [_vp, ctypes.POINTER(ProjectDesc), ctypes.POINTER(_vp)]),
+    'sbm_project_unload': (ctypes.c_int, [_vp]),
+    'sbm_residuals_batch': (ctypes.c_int, [_vp, _vp, _i32, _opts_p, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'sbm_jacobian_batch': (ctypes.c_int, [_vp, _vp, _i32, _opts_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'sbm_project_scratch_bytes': (ctypes.c_int64, [_vp, _i32, _i32]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library(build_if_missing=True):
+    """Load libsbm_hip.so (building it with hipcc first if allowed).  Raises if unavailable."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = build.CORE_LIB
+        if build_if_missing:
+            path = build.build_core()
+        if not os.path.exists(path):
+            raise SbmError("libsbm_hip.so not found at %s: build it with __graft_entry__.build()" % path)
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sbm_abi_version() != 1:
+            raise SbmError("libsbm_hip.so ABI %d, python binding expects 1" % lib.sbm_abi_version())
+        _lib = lib
+        return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load_library().sbm_last_error()
+        raise SbmError("%s failed (%d): %s" % (what or 'sbm call', rc, msg.decode() if msg else '?'))
+
+
+def np_ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def dev_ptr(t):
+    """void* of a torch CUDA tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None):
+    """IntegratorOpts from keywords.  For 'rk4' give h0 or (n_steps, t_end)."""
+    if isinstance(method, str):
+        key = method.lower()
+        if key in ('dopri45', 'dopri5', 'rk45'):
+            m = SBM_DOPRI45
+        elif key in ('rk4', 'rk4_fixed'):
+            m = SBM_RK4_FIXED
+        else:
+            raise ValueError("unknown integrator %r (use 'dopri45' or 'rk4')" % method)
+    else:
+        m = int(method)
+    if m == SBM_RK4_FIXED and not h0 > 0.0:
+        if n_steps is None or t_end is None:
+            raise ValueError("rk4 needs h0, or n_steps together with t_end")
+        h0 = float(t_end) / int(n_steps)
+    return IntegratorOpts(m, int(max_steps), float(rtol), float(atol), float(h0))
+
+
+# ---------------------------------------------------------------------------
+# contexts and models
+# ---------------------------------------------------------------------------
+class Context(object):
+    """One per device (per thread of use).  ``stream``: raw hipStream_t handle or None."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        check(self.lib.sbm_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h)),
+              'sbm_ctx_create')
+        self.handle = h
+        self.device = int(device)
+
+    def synchronize(self):
+        check(self.lib.sbm_ctx_synchronize(self.handle), 'sbm_ctx_synchronize')
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.sbm_ctx_destroy(self.handle)
+            self.handle = None
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context per device; device defaults to LOCAL_RANK (one process per GPU) or 0."""
+    if device is None:
+        device = int(os.environ.get('LOCAL_RANK', '0'))
+        # a single visible device is always index 0
+        try:
+            import torch
+            if torch.cuda.is_available() and device >= torch.cuda.device_count():
+                device = 0
+        except Exception:
+            pass
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class LoadedModel(object):
+    def __init__(self, ctx, plugin_path):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        h = ctypes.c_void_p()
+        check(self.lib.sbm_model_load(ctx.handle, os.fsencode(plugin_path), ctypes.byref(h)), 'sbm_model_load')
+        self.handle = h
+        nv, npar, nk = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        name = ctypes.create_string_buffer(64)
+        check(self.lib.sbm_model_info(h, ctypes.byref(nv), ctypes.byref(npar), ctypes.byref(nk), name, 64),
+              'sbm_model_info')
+        self.n_vars, self.n_params, self.n_sens = nv.value, npar.value, nk.value
+        self.name = name.value.decode()
+
+    # -- host-pointer calls (numpy in / numpy out) ---------------------------
+    def simulate_host(self, P, t_out, y0, opts):
+        P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, self.n_params)
+        t_out = np.ascontiguousarray(t_out, dtype=np.float64)
+        V, n_t = P.shape[0], t_out.shape[0]
+        if y0 is not None:
+            y0 = np.ascontiguousarray(y0, dtype=np.float64)
+            if y0.shape != (self.n_vars,):
+                raise ValueError("init_conditions must have shape (%d,)" % self.n_vars)
+        Y = np.empty((V, n_t, self.n_vars))
+        st = np.zeros(V, dtype=np.int32)
+        ns = np.zeros(V, dtype=np.int32)
+        nr = np.zeros(V, dtype=np.int32)
+        check(self.lib.sbm_simulate_batch_host(self.handle, np_ptr(P), V, np_ptr(t_out), n_t, np_ptr(y0),
+                                               ctypes.byref(opts), np_ptr(Y), np_ptr(st), np_ptr(ns), np_ptr(nr)),
+              'sbm_simulate_batch_host')
+        return Y, st, ns, nr
+
+    def sens_host(self, P, t_out, yS0, opts):
+        P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, self.n_params)
+        t_out = np.ascontiguousarray(t_out, dtype=np.float64)
+        V, n_t = P.shape[0], t_out.shape[0]
+        if yS0 is not None:
+            yS0 = np.ascontiguousarray(yS0, dtype=np.float64)
+            if yS0.shape != (self.n_vars * (1 + self.n_sens),):
+                raise ValueError("init_conditions must have shape (%d,)" % (self.n_vars * (1 + self.n_sens)))
+        Y = np.empty((V, n_t, self.n_vars))
+        S = np.empty((V, n_t, self.n_vars, self.n_sens))
+        st = np.zeros(V, dtype=np.int32)
+        ns = np.zeros(V, dtype=np.int32)
+        nr = np.zeros(V, dtype=np.int32)
+        check(self.lib.sbm_sens_batch_host(self.handle, np_ptr(P), V, np_ptr(t_out), n_t, np_ptr(yS0),
+                                           ctypes.byref(opts), np_ptr(Y), np_ptr(S), np_ptr(st), np_ptr(ns),
+                                           np_ptr(nr)), 'sbm_sens_batch_host')
+        return Y, S, st, ns, nr
+
+    # -- device-pointer calls (torch CUDA tensors; asynchronous) -------------
+    def simulate_dev(self, P, t_out, y0, opts, Y, status=None, n_steps=None, n_reject=None):
+        V, n_t = P.shape[0], t_out.shape[0]
+        check(self.lib.sbm_simulate_batch(self.handle, dev_ptr(P), V, dev_ptr(t_out), n_t, dev_ptr(y0),
+                                          ctypes.byref(opts), dev_ptr(Y), dev_ptr(status), dev_ptr(n_steps),
+                                          dev_ptr(n_reject)), 'sbm_simulate_batch')
+
+    def sens_dev(self, P, t_out, yS0, opts, Y, S, status=None, n_steps=None, n_reject=None):
+        V, n_t = P.shape[0], t_out.shape[0]
+        check(self.lib.sbm_sens_batch(self.handle, dev_ptr(P), V, dev_ptr(t_out), n_t, dev_ptr(yS0),
+                                      ctypes.byref(opts), dev_ptr(Y), dev_ptr(S), dev_ptr(status),
+                                      dev_ptr(n_steps), dev_ptr(n_reject)), 'sbm_sens_batch')
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.sbm_model_unload(self.handle)
+            self.handle = None

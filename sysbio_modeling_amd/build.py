@@ -1,0 +1,112 @@
+"""In-tree native builds (hipcc for gfx950, gcc for the C RHS used by the oracle).
+
+Everything lands in ``sysbio_modeling_amd/_build/`` so that the shared objects
+travel with the repository snapshot to the GPU box (they are git-ignored).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+CSRC_DIR = os.path.join(PKG_DIR, 'csrc')
+MODELS_DIR = os.path.join(CSRC_DIR, 'models')
+BUILD_DIR = os.path.join(PKG_DIR, '_build')
+GEN_DIR = os.path.join(BUILD_DIR, 'gen')
+CORE_LIB = os.path.join(BUILD_DIR, 'libsbm_hip.so')
+OFFLOAD_ARCH = 'gfx950'
+
+
+class BuildError(RuntimeError):
+    pass
+
+
+def hipcc_path():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise BuildError("hipcc not found: the HIP kernels cannot be built (set HIPCC or install ROCm)")
+
+
+def _run(cmd, what):
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise BuildError("%s failed (%s):\n%s" % (what, " ".join(cmd), proc.stdout))
+    return proc.stdout
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _core_sources():
+    srcs = [os.path.join(CSRC_DIR, f) for f in ('sbm_core.hip', 'sbm_plugin.h')]
+    srcs.append(os.path.join(REPO_DIR, 'include', 'sbm.h'))
+    return srcs
+
+
+def build_core(force=False, extra_flags=()):
+    """libsbm_hip.so: C ABI, contexts, model loading, project assembly kernels."""
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    srcs = _core_sources()
+    if not force and _newer(CORE_LIB, srcs):
+        return CORE_LIB
+    cmd = [hipcc_path(), '--offload-arch=' + OFFLOAD_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-Wall', '-Wno-unused-function', *extra_flags,
+           os.path.join(CSRC_DIR, 'sbm_core.hip'), '-o', CORE_LIB, '-ldl']
+    _run(cmd, 'build of libsbm_hip.so')
+    return CORE_LIB
+
+
+def plugin_path(name):
+    return os.path.join(BUILD_DIR, 'sbm_model_%s.so' % name)
+
+
+def build_plugin(name, header_path, force=False, extra_flags=()):
+    """sbm_model_<name>.so from a generated model header."""
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    out = plugin_path(name)
+    srcs = [header_path, os.path.join(CSRC_DIR, 'sbm_plugin_main.hip'),
+            os.path.join(CSRC_DIR, 'sbm_integrators.hpp'), os.path.join(CSRC_DIR, 'sbm_plugin.h'),
+            os.path.join(REPO_DIR, 'include', 'sbm.h')]
+    if not force and _newer(out, srcs):
+        return out
+    cmd = [hipcc_path(), '--offload-arch=' + OFFLOAD_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-DSBM_MODEL_HEADER="%s"' % os.path.abspath(header_path), *extra_flags,
+           os.path.join(CSRC_DIR, 'sbm_plugin_main.hip'), '-o', out]
+    _run(cmd, 'build of model plugin %s' % name)
+    return out
+
+
+def build_c_rhs(name, c_source, force=False):
+    """Compile a generated C right-hand side (oracle / CPU-baseline use only)."""
+    os.makedirs(GEN_DIR, exist_ok=True)
+    digest = hashlib.sha1(c_source.encode()).hexdigest()[:12]
+    c_path = os.path.join(GEN_DIR, 'rhs_%s_%s.c' % (name, digest))
+    so_path = os.path.join(GEN_DIR, 'rhs_%s_%s.so' % (name, digest))
+    if os.path.exists(so_path) and not force:
+        return so_path
+    with open(c_path, 'w') as fh:
+        fh.write(c_source)
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc is None:
+        raise BuildError("no C compiler for the oracle RHS")
+    _run([cc, '-O2', '-fPIC', '-shared', '-o', so_path, c_path, '-lm'], 'build of C RHS %s' % name)
+    return so_path
+
+
+def write_generated_header(name, hip_source):
+    """Header for a user model (zoo models are committed under csrc/models/)."""
+    os.makedirs(GEN_DIR, exist_ok=True)
+    digest = hashlib.sha1(hip_source.encode()).hexdigest()[:12]
+    path = os.path.join(GEN_DIR, '%s_%s.hpp' % (name, digest))
+    if not os.path.exists(path):
+        with open(path, 'w') as fh:
+            fh.write(hip_source)
+    return path, digest

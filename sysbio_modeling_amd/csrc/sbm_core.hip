@@ -1,0 +1,788 @@
+// sbm_core.hip -- libsbm_hip.so: the C ABI of include/sbm.h.
+//
+// Contexts, plugin loading, batched simulate / sensitivity entry points, and the
+// model-independent Project kernels:
+//   k_gather_params   theta -> per-experiment parameter vectors
+//                     (Project.get_experiment_parameters, project/base_project.py:343-363)
+//   k_assemble        fused measurement sampling + 'direct'/'sum' mapping + linear scale
+//                     factors + weighted residuals + log-parameter chain rule + scaled
+//                     Jacobian (base_project.py:365-391,443-488; project/utils.py:10-89;
+//                     loss_functions/squared_loss/squared_loss_function.py:27-80;
+//                     linear_scale_factor.py:27-42)
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "sbm_plugin.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+static int sbm_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define SBM_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) return sbm_fail(-2, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+enum { SBM_E_ARG = -1, SBM_E_HIP = -2, SBM_E_PLUGIN = -3 };
+
+// ---------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------
+struct sbm_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+};
+
+struct sbm_model {
+  sbm_ctx* ctx;
+  void* dl;
+  sbm_plugin_info_t info;
+  sbm_plugin_launch_fn launch;
+};
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int reserve(size_t want) {
+    if (want <= n) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) return -1;
+    n = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+struct sbm_project {
+  sbm_model* model;
+  int E, q, R, G, NPR, NSP, compat;
+  int n_params, n_vars, n_sens;
+  int n_t_max;  // longest per-experiment grid
+  // static device data
+  DevBuf<int32_t> pmap, sens_col, tgrid_off, grid_len, row_exp, row_tidx, row_var_off, row_vars, row_sf,
+      prior_idx, inv_ptr, inv_m, sfp_group;
+  DevBuf<double> pfixed, tgrid, row_data, row_sigma, prior_mean, prior_sigma, sfp_mean, sfp_sigma;
+  // per-call scratch, grown on demand
+  DevBuf<double> P, Y, S, sims, sf;
+  DevBuf<int32_t> traj_status, traj_steps, traj_rej, goff, glen;
+  int scratch_V = 0;
+};
+
+extern "C" const char* sbm_last_error(void) { return g_err; }
+extern "C" int sbm_abi_version(void) { return SBM_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" int sbm_ctx_create(int device, void* stream, sbm_ctx** out) {
+  if (!out) return sbm_fail(SBM_E_ARG, "sbm_ctx_create: out is NULL");
+  int n = 0;
+  SBM_HIP(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return sbm_fail(SBM_E_ARG, "sbm_ctx_create: device %d of %d", device, n);
+  SBM_HIP(hipSetDevice(device));
+  sbm_ctx* c = new sbm_ctx();
+  c->device = device;
+  // NULL = the device's default (null) stream, which is also what torch enqueues on
+  // unless told otherwise: copies made by the caller and our kernels stay ordered
+  c->stream = (hipStream_t)stream;
+  c->own_stream = false;
+  *out = c;
+  return 0;
+}
+
+extern "C" int sbm_ctx_destroy(sbm_ctx* c) {
+  if (!c) return 0;
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" int sbm_ctx_synchronize(sbm_ctx* c) {
+  if (!c) return sbm_fail(SBM_E_ARG, "sbm_ctx_synchronize: ctx is NULL");
+  SBM_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int sbm_ctx_device(const sbm_ctx* c) { return c ? c->device : -1; }
+
+// ---------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------
+extern "C" int sbm_model_load(sbm_ctx* ctx, const char* path, sbm_model** out) {
+  if (!ctx || !path || !out) return sbm_fail(SBM_E_ARG, "sbm_model_load: NULL argument");
+  SBM_HIP(hipSetDevice(ctx->device));
+  void* dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!dl) return sbm_fail(SBM_E_PLUGIN, "dlopen(%s): %s", path, dlerror());
+  auto info_fn = (sbm_plugin_info_fn)dlsym(dl, "sbm_plugin_info");
+  auto launch_fn = (sbm_plugin_launch_fn)dlsym(dl, "sbm_plugin_launch");
+  if (!info_fn || !launch_fn) {
+    dlclose(dl);
+    return sbm_fail(SBM_E_PLUGIN, "%s is not an sbm model plugin", path);
+  }
+  sbm_model* m = new sbm_model();
+  m->ctx = ctx;
+  m->dl = dl;
+  m->launch = launch_fn;
+  memset(&m->info, 0, sizeof(m->info));
+  info_fn(&m->info);
+  if (m->info.abi != SBM_PLUGIN_ABI) {
+    int abi = m->info.abi;
+    dlclose(dl);
+    delete m;
+    return sbm_fail(SBM_E_PLUGIN, "%s: plugin ABI %d, library expects %d", path, abi, SBM_PLUGIN_ABI);
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int sbm_model_unload(sbm_model* m) {
+  if (!m) return 0;
+  // the plugin's code object stays registered with the HIP runtime: do not dlclose
+  delete m;
+  return 0;
+}
+
+extern "C" int sbm_model_info(const sbm_model* m, int32_t* n_vars, int32_t* n_params, int32_t* n_sens,
+                              char* name_buf, int32_t name_buf_len) {
+  if (!m) return sbm_fail(SBM_E_ARG, "sbm_model_info: model is NULL");
+  if (n_vars) *n_vars = m->info.n_vars;
+  if (n_params) *n_params = m->info.n_params;
+  if (n_sens) *n_sens = m->info.n_sens;
+  if (name_buf && name_buf_len > 0) {
+    strncpy(name_buf, m->info.name, name_buf_len - 1);
+    name_buf[name_buf_len - 1] = 0;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// batched integration
+// ---------------------------------------------------------------------------
+static int check_opts(const sbm_integrator_opts* o, const char* who) {
+  if (!o) return sbm_fail(SBM_E_ARG, "%s: opts is NULL", who);
+  if (o->method == SBM_RK4_FIXED) {
+    if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: RK4 needs h0 > 0", who);
+  } else if (o->method == SBM_DOPRI45) {
+    if (!(o->rtol > 0.0) || !(o->atol > 0.0)) return sbm_fail(SBM_E_ARG, "%s: DOPRI45 needs rtol, atol > 0", who);
+  } else {
+    return sbm_fail(SBM_E_ARG, "%s: unknown method %d", who, o->method);
+  }
+  return 0;
+}
+
+static int launch(sbm_model* m, int kind, const sbm_kernel_args& a, const char* who) {
+  SBM_HIP(hipSetDevice(m->ctx->device));
+  int e = m->launch(kind, &a, (void*)m->ctx->stream);
+  if (e != 0) return sbm_fail(SBM_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString((hipError_t)e));
+  return 0;
+}
+
+extern "C" int sbm_simulate_batch(sbm_model* m, const double* P, int32_t V, const double* t_out, int32_t n_t,
+                                  const double* y0, const sbm_integrator_opts* opts, double* Y, int32_t* status,
+                                  int32_t* n_steps, int32_t* n_reject) {
+  if (!m || !P || !t_out || !Y) return sbm_fail(SBM_E_ARG, "sbm_simulate_batch: NULL argument");
+  if (V < 0 || n_t < 0) return sbm_fail(SBM_E_ARG, "sbm_simulate_batch: negative size");
+  int rc = check_opts(opts, "sbm_simulate_batch");
+  if (rc) return rc;
+  if (V == 0 || n_t == 0) return 0;
+  sbm_kernel_args a;
+  memset(&a, 0, sizeof(a));
+  a.P = P; a.t_out = t_out; a.y0 = y0; a.Y = Y;
+  a.status = status; a.n_steps = n_steps; a.n_reject = n_reject;
+  a.n_traj = V; a.n_t = n_t; a.opts = *opts;
+  return launch(m, SBM_KIND_STATE, a, "sbm_simulate_batch");
+}
+
+extern "C" int sbm_sens_batch(sbm_model* m, const double* P, int32_t V, const double* t_out, int32_t n_t,
+                              const double* yS0, const sbm_integrator_opts* opts, double* Y, double* S,
+                              int32_t* status, int32_t* n_steps, int32_t* n_reject) {
+  if (!m || !P || !t_out || !S) return sbm_fail(SBM_E_ARG, "sbm_sens_batch: NULL argument");
+  if (V < 0 || n_t < 0) return sbm_fail(SBM_E_ARG, "sbm_sens_batch: negative size");
+  int rc = check_opts(opts, "sbm_sens_batch");
+  if (rc) return rc;
+  if (V == 0 || n_t == 0) return 0;
+  sbm_kernel_args a;
+  memset(&a, 0, sizeof(a));
+  a.P = P; a.t_out = t_out;
+  a.y0 = yS0; a.s0 = yS0 ? yS0 + m->info.n_vars : nullptr;
+  a.Y = Y; a.S = S;
+  a.status = status; a.n_steps = n_steps; a.n_reject = n_reject;
+  a.n_traj = V; a.n_t = n_t; a.opts = *opts;
+  return launch(m, SBM_KIND_SENS, a, "sbm_sens_batch");
+}
+
+// ---- host-pointer variants -------------------------------------------------
+namespace {
+struct HostStage {
+  std::vector<void*> allocs;
+  ~HostStage() {
+    for (void* p : allocs) (void)hipFree(p);
+  }
+  template <class T>
+  T* up(const T* h, size_t n, hipStream_t s) {
+    if (!h || n == 0) return nullptr;
+    T* d = nullptr;
+    if (hipMalloc((void**)&d, n * sizeof(T)) != hipSuccess) return nullptr;
+    allocs.push_back(d);
+    if (hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+    return d;
+  }
+  template <class T>
+  T* dev(size_t n) {
+    if (n == 0) return nullptr;
+    T* d = nullptr;
+    if (hipMalloc((void**)&d, n * sizeof(T)) != hipSuccess) return nullptr;
+    allocs.push_back(d);
+    return d;
+  }
+};
+}  // namespace
+
+#define SBM_NEED(ptr, what) \
+  if (!(ptr)) return sbm_fail(SBM_E_HIP, "%s: device staging failed (out of memory?)", what)
+
+extern "C" int sbm_simulate_batch_host(sbm_model* m, const double* P, int32_t V, const double* t_out, int32_t n_t,
+                                       const double* y0, const sbm_integrator_opts* opts, double* Y,
+                                       int32_t* status, int32_t* n_steps, int32_t* n_reject) {
+  if (!m || !P || !t_out || !Y) return sbm_fail(SBM_E_ARG, "sbm_simulate_batch_host: NULL argument");
+  if (V <= 0 || n_t <= 0) return V < 0 || n_t < 0 ? sbm_fail(SBM_E_ARG, "negative size") : 0;
+  SBM_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  const int nv = m->info.n_vars, np = m->info.n_params;
+  HostStage st;
+  double* dP = st.up(P, (size_t)V * np, s); SBM_NEED(dP, "simulate");
+  double* dt = st.up(t_out, (size_t)n_t, s); SBM_NEED(dt, "simulate");
+  double* dy0 = y0 ? st.up(y0, (size_t)nv, s) : nullptr;
+  double* dY = st.dev<double>((size_t)V * n_t * nv); SBM_NEED(dY, "simulate");
+  int32_t* dst = st.dev<int32_t>((size_t)V * 3); SBM_NEED(dst, "simulate");
+  int rc = sbm_simulate_batch(m, dP, V, dt, n_t, dy0, opts, dY, dst, dst + V, dst + 2 * V);
+  if (rc) return rc;
+  SBM_HIP(hipMemcpyAsync(Y, dY, (size_t)V * n_t * nv * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (status) SBM_HIP(hipMemcpyAsync(status, dst, V * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (n_steps) SBM_HIP(hipMemcpyAsync(n_steps, dst + V, V * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (n_reject) SBM_HIP(hipMemcpyAsync(n_reject, dst + 2 * V, V * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  SBM_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int sbm_sens_batch_host(sbm_model* m, const double* P, int32_t V, const double* t_out, int32_t n_t,
+                                   const double* yS0, const sbm_integrator_opts* opts, double* Y, double* S,
+                                   int32_t* status, int32_t* n_steps, int32_t* n_reject) {
+  if (!m || !P || !t_out || !S) return sbm_fail(SBM_E_ARG, "sbm_sens_batch_host: NULL argument");
+  if (V <= 0 || n_t <= 0) return V < 0 || n_t < 0 ? sbm_fail(SBM_E_ARG, "negative size") : 0;
+  SBM_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  const int nv = m->info.n_vars, np = m->info.n_params, nk = m->info.n_sens;
+  HostStage st;
+  double* dP = st.up(P, (size_t)V * np, s); SBM_NEED(dP, "sens");
+  double* dt = st.up(t_out, (size_t)n_t, s); SBM_NEED(dt, "sens");
+  double* d0 = yS0 ? st.up(yS0, (size_t)nv * (1 + nk), s) : nullptr;
+  double* dY = st.dev<double>((size_t)V * n_t * nv); SBM_NEED(dY, "sens");
+  double* dS = st.dev<double>((size_t)V * n_t * nv * nk); SBM_NEED(dS, "sens");
+  int32_t* dst = st.dev<int32_t>((size_t)V * 3); SBM_NEED(dst, "sens");
+  int rc = sbm_sens_batch(m, dP, V, dt, n_t, d0, opts, dY, dS, dst, dst + V, dst + 2 * V);
+  if (rc) return rc;
+  if (Y) SBM_HIP(hipMemcpyAsync(Y, dY, (size_t)V * n_t * nv * sizeof(double), hipMemcpyDeviceToHost, s));
+  SBM_HIP(hipMemcpyAsync(S, dS, (size_t)V * n_t * nv * nk * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (status) SBM_HIP(hipMemcpyAsync(status, dst, V * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (n_steps) SBM_HIP(hipMemcpyAsync(n_steps, dst + V, V * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (n_reject) SBM_HIP(hipMemcpyAsync(n_reject, dst + 2 * V, V * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  SBM_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ===========================================================================
+// Project
+// ===========================================================================
+// trajectory id = v * E + e
+
+// theta -> P.  grid: ceil(V*E*NP / 256)
+__global__ void k_gather_params(const double* __restrict__ Theta, const int32_t* __restrict__ pmap,
+                                const double* __restrict__ pfixed, int V, int E, int NP, int q,
+                                double* __restrict__ P) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)V * E * NP;
+  if (idx >= total) return;
+  const int m = (int)(idx % NP);
+  const size_t ve = idx / NP;
+  const int e = (int)(ve % E);
+  const size_t v = ve / E;
+  const int g = pmap[e * NP + m];
+  P[idx] = (g >= 0) ? exp(Theta[v * q + g]) : pfixed[e * NP + m];
+}
+
+// per-trajectory grid descriptors (same for every vector): grid = ceil(V*E/256)
+__global__ void k_fill_grids(const int32_t* __restrict__ tgrid_off, int V, int E, int32_t* __restrict__ goff,
+                             int32_t* __restrict__ glen) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= V * E) return;
+  const int e = idx % E;
+  goff[idx] = tgrid_off[e];
+  glen[idx] = tgrid_off[e + 1] - tgrid_off[e];
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red /*[4]*/) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+struct AssembleArgs {
+  // static project data
+  int E, q, R, G, NPR, NSP, NP, NV, NK, n_t, compat;
+  const int32_t *row_exp, *row_tidx, *row_var_off, *row_vars, *row_sf, *prior_idx, *sfp_group;
+  const double *row_data, *row_sigma, *prior_mean, *prior_sigma, *sfp_mean, *sfp_sigma;
+  const int32_t *inv_ptr, *inv_m;  // [E][q+1] CSR: model params mapped to project column c in experiment e
+  const int32_t* sens_col;
+  // per call
+  const double* Theta;        // [V][q]
+  const double* Y;            // [V*E][n_t][NV]
+  const double* S;            // [V*E][n_t][NV][NK]   (nullable: residuals only)
+  const int32_t* traj_status; // [V*E]
+  const int32_t* traj_steps;  // [V*E]
+  double* sims;               // [V][R]       (scratch or user)
+  double* Rout;               // [V][R+NPR]
+  double* sf;                 // [V][G]       nullable
+  double* norms;              // [V]          nullable
+  int32_t* status;            // [V]          nullable
+  int32_t* n_steps;           // [V]          nullable: sum over the vector's trajectories
+  double* J;                  // [V][R+NPR][q] nullable
+  double* Jmodel;             // [V][R][q]     nullable
+  double* grad;               // [V][q]        nullable
+  double* sf_grad;            // [V][G][q]     nullable
+};
+
+// One block (256 threads) per parameter vector.
+// LDS: sims[R], B[G], sde[G], sds[G], dB[G][q] (Jacobian mode), reduction scratch.
+__global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int v = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int R = a.R, G = a.G, q = a.q, E = a.E;
+  double* s_sim = smem;                 // [R]
+  double* s_res = s_sim + R;            // [R]   weighted residuals
+  double* s_B = s_res + R;              // [max(G,1)]
+  double* s_sde = s_B + (G > 0 ? G : 1);
+  double* s_sds = s_sde + (G > 0 ? G : 1);
+  double* s_red = s_sds + (G > 0 ? G : 1);  // [4]
+  double* s_dB = s_red + 4;                 // [2][G][q]
+  __shared__ int s_bad;
+
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  // status of the vector = worst status of its trajectories
+  int st = 0, steps = 0;
+  for (int e = tid; e < E; e += blockDim.x) {
+    st = max(st, a.traj_status[(size_t)v * E + e]);
+    steps += a.traj_steps ? a.traj_steps[(size_t)v * E + e] : 0;
+  }
+  if (st != 0) atomicMax(&s_bad, st);
+  if (a.n_steps) {
+    const double tot = block_sum((double)steps, s_red);
+    if (tid == 0) a.n_steps[v] = (int32_t)tot;
+  }
+
+  // ---- 1. sample + map: sims[r] = sum_{var in vars(r)} Y[traj][tidx][var] ----
+  for (int r = tid; r < R; r += blockDim.x) {
+    const int e = a.row_exp[r];
+    const size_t base = (((size_t)v * E + e) * a.n_t + a.row_tidx[r]) * a.NV;
+    double s = 0.0;
+    for (int k = a.row_var_off[r]; k < a.row_var_off[r + 1]; ++k) s += a.Y[base + a.row_vars[k]];
+    s_sim[r] = s;
+    if (!(s == s)) atomicMax(&s_bad, (int)SBM_NON_FINITE);
+  }
+  __syncthreads();
+  const int bad = s_bad;
+  if (a.status && tid == 0) a.status[v] = bad;
+
+  const int RT = R + a.NPR + a.NSP;
+  if (bad) {
+    // reference: NaN in simulations -> every residual / Jacobian entry is inf
+    // (squared_loss_function.py:28-32,46-50)
+    const double inf = __builtin_inf();
+    for (int r = tid; r < RT; r += blockDim.x) a.Rout[(size_t)v * RT + r] = inf;
+    if (a.sims) for (int r = tid; r < R; r += blockDim.x) a.sims[(size_t)v * R + r] = s_sim[r];
+    if (a.sf) for (int g = tid; g < G; g += blockDim.x) a.sf[(size_t)v * G + g] = __builtin_nan("");
+    if (a.norms && tid == 0) a.norms[v] = inf;
+    if (a.J) for (size_t i = tid; i < (size_t)RT * q; i += blockDim.x) a.J[(size_t)v * RT * q + i] = inf;
+    if (a.Jmodel) for (size_t i = tid; i < (size_t)R * q; i += blockDim.x) a.Jmodel[(size_t)v * R * q + i] = inf;
+    if (a.grad) for (int c = tid; c < q; c += blockDim.x) a.grad[(size_t)v * q + c] = inf;
+    if (a.sf_grad) for (int i = tid; i < G * q; i += blockDim.x) a.sf_grad[(size_t)v * G * q + i] = __builtin_nan("");
+    return;
+  }
+  if (a.sims) for (int r = tid; r < R; r += blockDim.x) a.sims[(size_t)v * R + r] = s_sim[r];
+
+  // ---- 2. scale factors B_g = sum(s d / sigma^2) / sum(s^2 / sigma^2) ----
+  for (int g = 0; g < G; ++g) {
+    double sde = 0.0, sds = 0.0;
+    for (int r = tid; r < R; r += blockDim.x) {
+      if (a.row_sf[r] == g) {
+        const double w = 1.0 / (a.row_sigma[r] * a.row_sigma[r]);
+        sde += s_sim[r] * a.row_data[r] * w;
+        sds += s_sim[r] * s_sim[r] * w;
+      }
+    }
+    sde = block_sum(sde, s_red);
+    sds = block_sum(sds, s_red);
+    if (tid == 0) {
+      s_sde[g] = sde;
+      s_sds[g] = sds;
+      s_B[g] = sde / sds;
+      if (a.sf) a.sf[(size_t)v * G + g] = sde / sds;
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. residuals ----
+  double nrm = 0.0;
+  for (int r = tid; r < RT; r += blockDim.x) {
+    double res;
+    if (r < R) {
+      const int g = a.row_sf[r];
+      const double B = g >= 0 ? s_B[g] : 1.0;
+      res = (B * s_sim[r] - a.row_data[r]) / a.row_sigma[r];
+      s_res[r] = res;
+    } else if (r < R + a.NPR) {
+      const int k = r - R;
+      res = (a.Theta[(size_t)v * q + a.prior_idx[k]] - a.prior_mean[k]) / a.prior_sigma[k];
+    } else {
+      const int k = r - R - a.NPR;  // (log B - prior)/sigma, linear_scale_factor.py:55-61
+      res = (log(s_B[a.sfp_group[k]]) - a.sfp_mean[k]) / a.sfp_sigma[k];
+    }
+    a.Rout[(size_t)v * RT + r] = res;
+    nrm += res * res;
+  }
+  nrm = block_sum(nrm, s_red);
+  if (a.norms && tid == 0) a.norms[v] = nrm;
+  if (!a.J && !a.Jmodel && !a.grad) return;
+
+  // ---- 4. model Jacobian with the log-parameter chain rule (base_project.py:450-455,482-485):
+  //      Jm[r][c] = exp(theta_c) * sum_{model params m of experiment e reading slot c} sum_{var in vars(r)} S[var][m]
+  // pass A: write Jm, accumulate per SF group the two products J^T (d/sigma^2), J^T (s/sigma^2)
+  double* Jv = a.J ? a.J + (size_t)v * RT * q : nullptr;
+  double* Jm = a.Jmodel ? a.Jmodel + (size_t)v * R * q : nullptr;
+  const double* th = a.Theta + (size_t)v * q;
+  double* s_jde = s_dB;                       // [G][q]  becomes dB/dtheta
+  double* s_jds = s_dB + (size_t)(G > 0 ? G : 1) * q;  // [G][q]
+  for (int i = tid; i < 2 * (G > 0 ? G : 1) * q; i += blockDim.x) s_dB[i] = 0.0;
+  __syncthreads();
+
+  const int nthr = blockDim.x;
+  const int cw = q < nthr ? q : nthr;  // columns handled side by side (consecutive threads -> consecutive columns)
+  const int rpp = nthr / cw;           // row lanes
+  const int cl = tid % cw, rl = tid / cw;
+  for (int c0 = 0; c0 < q; c0 += cw) {
+    const int c = c0 + cl;
+    if (c >= q || rl >= rpp) continue;
+    const double dth = exp(th[c]);
+    int gcur = -1;
+    double jde = 0.0, jds = 0.0;
+    for (int r = rl; r < R; r += rpp) {
+      const int e = a.row_exp[r];
+      const size_t base = ((((size_t)v * E + e) * a.n_t + a.row_tidx[r]) * a.NV) * a.NK;
+      double jm = 0.0;
+      for (int k = a.inv_ptr[e * (q + 1) + c]; k < a.inv_ptr[e * (q + 1) + c + 1]; ++k) {
+        const int sc = a.sens_col[a.inv_m[k]];
+        if (sc < 0) continue;
+        for (int kk = a.row_var_off[r]; kk < a.row_var_off[r + 1]; ++kk)
+          jm += a.S[base + (size_t)a.row_vars[kk] * a.NK + sc];
+      }
+      jm *= dth;
+      if (Jm) Jm[(size_t)r * q + c] = jm;
+      if (Jv) Jv[(size_t)r * q + c] = jm;
+      const int g = a.row_sf[r];
+      if (g != gcur) {  // rows of one group are mostly consecutive: flush on change
+        if (gcur >= 0) { atomicAdd(&s_jde[gcur * q + c], jde); atomicAdd(&s_jds[gcur * q + c], jds); }
+        gcur = g; jde = 0.0; jds = 0.0;
+      }
+      if (g >= 0) {
+        const double w = 1.0 / (a.row_sigma[r] * a.row_sigma[r]);
+        jde += jm * a.row_data[r] * w;
+        jds += jm * s_sim[r] * w;
+      }
+    }
+    if (gcur >= 0) { atomicAdd(&s_jde[gcur * q + c], jde); atomicAdd(&s_jds[gcur * q + c], jds); }
+  }
+  __syncthreads();
+  // dB_g/dtheta_c = jde/sds - 2 sde jds / sds^2   (linear_scale_factor.py:33-42)
+  for (int i = tid; i < G * q; i += blockDim.x) {
+    const int g = i / q;
+    const double sds = s_sds[g], sde = s_sde[g];
+    const double db = s_jde[i] / sds - 2.0 * sde * s_jds[i] / (sds * sds);
+    s_dB[i] = db;
+    if (a.sf_grad) a.sf_grad[(size_t)v * G * q + i] = db;
+  }
+  __syncthreads();
+
+  // pass B: J = B*Jm + sim (x) dB ; reference_compat: not divided by sigma, prior rows zero
+  if (Jv) {
+    for (size_t i = tid; i < (size_t)RT * q; i += blockDim.x) {
+      const int r = (int)(i / q), c = (int)(i - (size_t)r * q);
+      double val;
+      if (r < R) {
+        const int g = a.row_sf[r];
+        val = Jv[i];
+        if (g >= 0) val = s_B[g] * val + s_sim[r] * s_dB[g * q + c];
+        if (!a.compat) val /= a.row_sigma[r];
+      } else if (r < R + a.NPR) {
+        const int k = r - R;
+        val = (!a.compat && a.prior_idx[k] == c) ? 1.0 / a.prior_sigma[k] : 0.0;
+      } else {
+        const int k = r - R - a.NPR;  // (dB/dtheta)/B, linear_scale_factor.py:44-53
+        const int g = a.sfp_group[k];
+        val = s_dB[g * q + c] / s_B[g];
+        if (!a.compat) val /= a.sfp_sigma[k];
+      }
+      Jv[i] = val;
+    }
+  }
+  // gradient of 0.5*sum r^2: (J^T r) with the Jacobian as returned (reference :803-805)
+  if (a.grad) {
+    __syncthreads();
+    for (int c = tid; c < q; c += blockDim.x) {
+      double gsum = 0.0;
+      if (Jv) {
+        for (int r = 0; r < RT; ++r) {
+          const double res = a.Rout[(size_t)v * RT + r];
+          gsum += Jv[(size_t)r * q + c] * res;
+        }
+      }
+      a.grad[(size_t)v * q + c] = gsum;
+    }
+  }
+}
+
+template <class T>
+static int upload(DevBuf<T>& b, const T* h, size_t n, hipStream_t s) {
+  if (n == 0) n = 1;  // keep pointers non-NULL
+  if (b.reserve(n)) return -1;
+  if (h && hipMemcpyAsync(b.p, h, (n) * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  return 0;
+}
+
+extern "C" int sbm_project_load(sbm_model* m, const sbm_project_desc* d, sbm_project** out) {
+  if (!m || !d || !out) return sbm_fail(SBM_E_ARG, "sbm_project_load: NULL argument");
+  const int E = d->n_experiments, q = d->n_project_params, R = d->n_rows, G = d->n_sf_groups,
+            NPR = d->n_prior_rows, NSP = d->n_sf_prior_rows, NP = m->info.n_params;
+  if (E <= 0 || q <= 0 || R < 0 || G < 0 || NPR < 0 || NSP < 0)
+    return sbm_fail(SBM_E_ARG, "sbm_project_load: bad sizes E=%d q=%d R=%d G=%d", E, q, R, G);
+  if (!d->pmap || !d->pfixed || !d->sens_col || !d->tgrid_off || !d->tgrid || (R && (!d->row_exp || !d->row_tidx ||
+      !d->row_var_off || !d->row_vars || !d->row_data || !d->row_sigma || !d->row_sf)))
+    return sbm_fail(SBM_E_ARG, "sbm_project_load: NULL array in descriptor");
+  // validate on the host: the kernels index with these
+  int n_t_max = 0;
+  for (int e = 0; e < E; ++e) {
+    const int len = d->tgrid_off[e + 1] - d->tgrid_off[e];
+    if (len <= 0) return sbm_fail(SBM_E_ARG, "sbm_project_load: experiment %d has no output times", e);
+    for (int k = d->tgrid_off[e] + 1; k < d->tgrid_off[e + 1]; ++k)
+      if (!(d->tgrid[k] >= d->tgrid[k - 1])) return sbm_fail(SBM_E_ARG, "sbm_project_load: tgrid of experiment %d not sorted", e);
+    if (d->tgrid[d->tgrid_off[e]] < 0.0) return sbm_fail(SBM_E_ARG, "sbm_project_load: negative output time");
+    n_t_max = len > n_t_max ? len : n_t_max;
+    for (int k = 0; k < NP; ++k) {
+      const int g = d->pmap[e * NP + k];
+      if (g >= q) return sbm_fail(SBM_E_ARG, "sbm_project_load: pmap[%d][%d]=%d >= q=%d", e, k, g, q);
+    }
+  }
+  for (int k = 0; k < NP; ++k)
+    if (d->sens_col[k] >= m->info.n_sens) return sbm_fail(SBM_E_ARG, "sbm_project_load: sens_col out of range");
+  for (int r = 0; r < R; ++r) {
+    const int e = d->row_exp[r];
+    if (e < 0 || e >= E) return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d experiment %d", r, e);
+    const int len = d->tgrid_off[e + 1] - d->tgrid_off[e];
+    if (d->row_tidx[r] < 0 || d->row_tidx[r] >= len) return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d time index", r);
+    if (d->row_var_off[r + 1] < d->row_var_off[r]) return sbm_fail(SBM_E_ARG, "sbm_project_load: row_var_off");
+    for (int k = d->row_var_off[r]; k < d->row_var_off[r + 1]; ++k)
+      if (d->row_vars[k] < 0 || d->row_vars[k] >= m->info.n_vars)
+        return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d maps to variable %d of %d", r, d->row_vars[k], m->info.n_vars);
+    if (d->row_sf[r] >= G) return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d sf group %d", r, d->row_sf[r]);
+    if (d->row_sigma[r] == 0.0) return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d has sigma 0", r);
+  }
+  for (int k = 0; k < NPR; ++k)
+    if (d->prior_idx[k] < 0 || d->prior_idx[k] >= q) return sbm_fail(SBM_E_ARG, "sbm_project_load: prior index");
+  for (int k = 0; k < NSP; ++k)
+    if (d->sf_prior_group[k] < 0 || d->sf_prior_group[k] >= G) return sbm_fail(SBM_E_ARG, "sbm_project_load: sf prior group");
+
+  SBM_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  sbm_project* p = new sbm_project();
+  p->model = m;
+  p->E = E; p->q = q; p->R = R; p->G = G; p->NPR = NPR; p->NSP = NSP; p->compat = d->reference_compat;
+  p->n_params = NP; p->n_vars = m->info.n_vars; p->n_sens = m->info.n_sens; p->n_t_max = n_t_max;
+
+  // inverse map: for experiment e and project column c, the model params that read it
+  std::vector<int32_t> inv_ptr((size_t)E * (q + 1), 0), inv_m;
+  for (int e = 0; e < E; ++e) {
+    for (int c = 0; c < q; ++c) {
+      inv_ptr[(size_t)e * (q + 1) + c] = (int32_t)inv_m.size();
+      for (int k = 0; k < NP; ++k)
+        if (d->pmap[e * NP + k] == c) inv_m.push_back(k);
+    }
+    inv_ptr[(size_t)e * (q + 1) + q] = (int32_t)inv_m.size();
+  }
+  std::vector<int32_t> glen(E);
+  for (int e = 0; e < E; ++e) glen[e] = d->tgrid_off[e + 1] - d->tgrid_off[e];
+  const int nvars_total = R ? d->row_var_off[R] : 0;
+  int bad = 0;
+  bad |= upload(p->pmap, d->pmap, (size_t)E * NP, s);
+  bad |= upload(p->pfixed, d->pfixed, (size_t)E * NP, s);
+  bad |= upload(p->sens_col, d->sens_col, (size_t)NP, s);
+  bad |= upload(p->tgrid_off, d->tgrid_off, (size_t)E + 1, s);
+  bad |= upload(p->tgrid, d->tgrid, (size_t)d->tgrid_off[E], s);
+  bad |= upload(p->grid_len, glen.data(), (size_t)E, s);
+  bad |= upload(p->row_exp, d->row_exp, (size_t)R, s);
+  bad |= upload(p->row_tidx, d->row_tidx, (size_t)R, s);
+  bad |= upload(p->row_var_off, d->row_var_off, (size_t)R + 1, s);
+  bad |= upload(p->row_vars, d->row_vars, (size_t)nvars_total, s);
+  bad |= upload(p->row_data, d->row_data, (size_t)R, s);
+  bad |= upload(p->row_sigma, d->row_sigma, (size_t)R, s);
+  bad |= upload(p->row_sf, d->row_sf, (size_t)R, s);
+  bad |= upload(p->prior_idx, d->prior_idx, (size_t)NPR, s);
+  bad |= upload(p->prior_mean, d->prior_mean, (size_t)NPR, s);
+  bad |= upload(p->prior_sigma, d->prior_sigma, (size_t)NPR, s);
+  bad |= upload(p->sfp_group, d->sf_prior_group, (size_t)NSP, s);
+  bad |= upload(p->sfp_mean, d->sf_prior_mean, (size_t)NSP, s);
+  bad |= upload(p->sfp_sigma, d->sf_prior_sigma, (size_t)NSP, s);
+  bad |= upload(p->inv_ptr, inv_ptr.data(), inv_ptr.size(), s);
+  bad |= upload(p->inv_m, inv_m.data(), inv_m.size(), s);
+  hipError_t e = hipStreamSynchronize(s);  // host vectors go out of scope
+  if (bad || e != hipSuccess) {
+    sbm_project_unload(p);
+    return sbm_fail(SBM_E_HIP, "sbm_project_load: device upload failed");
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" int sbm_project_unload(sbm_project* p) {
+  if (!p) return 0;
+  (void)hipSetDevice(p->model->ctx->device);
+  p->pmap.release(); p->sens_col.release(); p->tgrid_off.release(); p->grid_len.release(); p->row_exp.release();
+  p->row_tidx.release(); p->row_var_off.release(); p->row_vars.release(); p->row_sf.release(); p->prior_idx.release();
+  p->inv_ptr.release(); p->inv_m.release(); p->pfixed.release(); p->tgrid.release(); p->row_data.release();
+  p->row_sigma.release(); p->prior_mean.release(); p->prior_sigma.release();
+  p->sfp_group.release(); p->sfp_mean.release(); p->sfp_sigma.release();
+  p->P.release(); p->Y.release(); p->S.release(); p->sims.release(); p->sf.release();
+  p->traj_status.release(); p->traj_steps.release(); p->traj_rej.release(); p->goff.release(); p->glen.release();
+  delete p;
+  return 0;
+}
+
+extern "C" int64_t sbm_project_scratch_bytes(const sbm_project* p, int32_t V, int32_t with_sens) {
+  if (!p || V < 0) return -1;
+  const int64_t T = (int64_t)V * p->E;
+  int64_t b = T * p->n_params * 8 + T * p->n_t_max * p->n_vars * 8 + T * 5 * 4 + (int64_t)V * (p->R + p->G) * 8;
+  if (with_sens) b += T * p->n_t_max * p->n_vars * (int64_t)p->n_sens * 8;
+  return b;
+}
+
+static int project_run(sbm_project* p, const double* Theta, int V, const sbm_integrator_opts* opts, bool sens,
+                       double* sims, double* Rout, double* J, double* Jmodel, double* sf, double* sf_grad, double* norms,
+                       double* grad, int32_t* status, int32_t* n_steps, const char* who) {
+  if (!p || !Theta || !Rout) return sbm_fail(SBM_E_ARG, "%s: NULL argument", who);
+  if (V < 0) return sbm_fail(SBM_E_ARG, "%s: V < 0", who);
+  int rc = check_opts(opts, who);
+  if (rc) return rc;
+  if (V == 0) return 0;
+  sbm_model* m = p->model;
+  SBM_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  const size_t T = (size_t)V * p->E;
+  const int NV = p->n_vars, NK = p->n_sens, NP = p->n_params, nt = p->n_t_max;
+  // scratch reallocation must not race with kernels of an earlier call still using it
+  const bool grow = T * NP > p->P.n || T * nt * NV > p->Y.n || (sens && T * nt * NV * NK > p->S.n) ||
+                    T > p->traj_status.n || (size_t)V * p->R > p->sims.n;
+  if (grow) SBM_HIP(hipStreamSynchronize(s));
+  if (p->P.reserve(T * NP) || p->Y.reserve(T * nt * NV) || (sens && p->S.reserve(T * nt * NV * NK)) ||
+      p->traj_status.reserve(T) || p->traj_steps.reserve(T) || p->traj_rej.reserve(T) || p->goff.reserve(T) ||
+      p->glen.reserve(T) || p->sims.reserve((size_t)V * (p->R > 0 ? p->R : 1)))
+    return sbm_fail(SBM_E_HIP, "%s: out of device memory for %d vectors (%lld bytes of scratch)", who, V,
+                    (long long)sbm_project_scratch_bytes(p, V, sens));
+  if (p->scratch_V != V) {
+    hipLaunchKernelGGL(k_fill_grids, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, p->tgrid_off.p, V, p->E,
+                       p->goff.p, p->glen.p);
+    p->scratch_V = V;
+  }
+  {
+    const size_t total = T * NP;
+    hipLaunchKernelGGL(k_gather_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Theta, p->pmap.p,
+                       p->pfixed.p, V, p->E, NP, p->q, p->P.p);
+  }
+  sbm_kernel_args a;
+  memset(&a, 0, sizeof(a));
+  a.P = p->P.p; a.t_out = p->tgrid.p; a.grid_off = p->goff.p; a.grid_len = p->glen.p;
+  a.Y = p->Y.p; a.S = sens ? p->S.p : nullptr;
+  a.status = p->traj_status.p; a.n_steps = p->traj_steps.p; a.n_reject = p->traj_rej.p;
+  a.n_traj = (int32_t)T; a.n_t = nt; a.opts = *opts;
+  rc = launch(m, sens ? SBM_KIND_SENS : SBM_KIND_STATE, a, who);
+  if (rc) return rc;
+
+  AssembleArgs g;
+  memset(&g, 0, sizeof(g));
+  g.E = p->E; g.q = p->q; g.R = p->R; g.G = p->G; g.NPR = p->NPR; g.NSP = p->NSP; g.NP = NP; g.NV = NV; g.NK = NK; g.n_t = nt;
+  g.compat = p->compat;
+  g.row_exp = p->row_exp.p; g.row_tidx = p->row_tidx.p; g.row_var_off = p->row_var_off.p; g.row_vars = p->row_vars.p;
+  g.row_sf = p->row_sf.p; g.prior_idx = p->prior_idx.p; g.row_data = p->row_data.p; g.row_sigma = p->row_sigma.p;
+  g.prior_mean = p->prior_mean.p; g.prior_sigma = p->prior_sigma.p;
+  g.sfp_group = p->sfp_group.p; g.sfp_mean = p->sfp_mean.p; g.sfp_sigma = p->sfp_sigma.p; g.inv_ptr = p->inv_ptr.p; g.inv_m = p->inv_m.p;
+  g.sens_col = p->sens_col.p;
+  g.Theta = Theta; g.Y = p->Y.p; g.S = sens ? p->S.p : nullptr;
+  g.traj_status = p->traj_status.p; g.traj_steps = p->traj_steps.p;
+  g.sims = sims ? sims : p->sims.p; g.Rout = Rout; g.sf = sf; g.norms = norms; g.status = status; g.n_steps = n_steps;
+  g.J = sens ? J : nullptr; g.Jmodel = sens ? Jmodel : nullptr; g.grad = sens ? grad : nullptr;
+  g.sf_grad = sens ? sf_grad : nullptr;
+  const int Gn = p->G > 0 ? p->G : 1;
+  const size_t lds = sizeof(double) * ((size_t)2 * p->R + 3 * Gn + 4 + (size_t)2 * Gn * p->q);
+  if (lds > 160 * 1024) return sbm_fail(SBM_E_ARG, "%s: project too large for the assembly kernel (%zu B of LDS)", who, lds);
+  if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_assemble, dim3(V), dim3(256), lds, s, g);
+  SBM_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sbm_residuals_batch(sbm_project* p, const double* Theta, int32_t V, const sbm_integrator_opts* opts,
+                                   double* sims, double* Rout, double* sf, double* norms, int32_t* status,
+                                   int32_t* n_steps) {
+  return project_run(p, Theta, V, opts, false, sims, Rout, nullptr, nullptr, sf, nullptr, norms, nullptr, status, n_steps,
+                     "sbm_residuals_batch");
+}
+
+extern "C" int sbm_jacobian_batch(sbm_project* p, const double* Theta, int32_t V, const sbm_integrator_opts* opts,
+                                  double* sims, double* Rout, double* J, double* Jmodel, double* sf, double* sf_grad,
+                                  double* norms, double* grad, int32_t* status, int32_t* n_steps) {
+  if (!J && !Jmodel) return sbm_fail(SBM_E_ARG, "sbm_jacobian_batch: J and Jmodel both NULL");
+  if (grad && !J) return sbm_fail(SBM_E_ARG, "sbm_jacobian_batch: grad needs J");
+  return project_run(p, Theta, V, opts, true, sims, Rout, J, Jmodel, sf, sf_grad, norms, grad, status, n_steps,
+                     "sbm_jacobian_batch");
+}

@@ -1,0 +1,483 @@
+// sbm_integrators.hpp -- ODE / forward-sensitivity integrators for gfx950 (CDNA4).
+//
+// Replaces the per-trajectory hot loop of the reference:
+//   OdeModel.simulate       (model/ode_model.py:128-169)  -> state kernels
+//   OdeModel.calc_jacobian  (model/ode_model.py:83-126)   -> sensitivity kernels
+// which there is scipy.integrate.odeint (LSODA, Fortran) calling a Python RHS.
+//
+// Two mappings, chosen per kernel kind:
+//
+//  * sensitivity kernels: ONE TRAJECTORY PER WAVEFRONT.  The augmented state is
+//    the n x (1+k) matrix Z = [ y | S ]; lane c of the wave owns column c
+//    (lane 0 the state, lane 1+j the sensitivities w.r.t. parameter j) and keeps
+//    all n rows of it, for every Runge-Kutta stage, in VGPRs.  A column evolves
+//    as  z_c' = J_y(y) z_c + J_p[:, c]  and lane 0 as y' = f(y); y is broadcast
+//    from lane 0 (v_readfirstlane -> SGPRs), J_y / J_p / f are evaluated once per
+//    stage from scalar operands, and the sparse per-column product is unrolled
+//    with static indices (SbmModel::apply_col).  No LDS, no HBM traffic inside
+//    the step loop; step-size control is wave-uniform (no divergence).
+//
+//  * state-only kernels: ONE TRAJECTORY PER LANE (n is tiny; there is nothing to
+//    spread over a wave).  Parameters are loaded coalesced and parked in LDS,
+//    transposed to [param][lane] so that every access is conflict-free.
+//
+// The generated model header must define `struct SbmModel` (see
+// sysbio_modeling_amd/symbolic/emit.py::emit_hip) and may use SBM_RCP.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sbm_plugin.h"
+
+// ---------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------
+// 1/x: v_rcp_f64 (~24 good bits on gfx950... refined by two Newton steps to < 1 ulp-ish).
+// The IEEE division sequence (div_scale/div_fmas/div_fixup) costs about twice as much
+// and the RHS of rate-law models is dominated by reciprocals.
+__device__ __forceinline__ double sbm_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-x, r, 1.0);
+  r = fma(e, r, r);
+  return r;
+}
+#define SBM_RCP(x) sbm_rcp(x)
+
+__device__ __forceinline__ double sbm_bcast0(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float sbm_bcast0f(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ float sbm_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return sbm_bcast0f(v);
+}
+__device__ __forceinline__ double sbm_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return sbm_bcast0(v);
+}
+// NaN-propagating: a NaN anywhere must surface as a failed step
+__device__ __forceinline__ float sbm_nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
+
+// ---------------------------------------------------------------------------
+// Dormand-Prince 5(4) tableau (Hairer, Norsett, Wanner, vol. I, table 5.2)
+// ---------------------------------------------------------------------------
+namespace dp {
+constexpr double C2 = 1.0 / 5.0, C3 = 3.0 / 10.0, C4 = 4.0 / 5.0, C5 = 8.0 / 9.0;
+constexpr double A21 = 1.0 / 5.0;
+constexpr double A31 = 3.0 / 40.0, A32 = 9.0 / 40.0;
+constexpr double A41 = 44.0 / 45.0, A42 = -56.0 / 15.0, A43 = 32.0 / 9.0;
+constexpr double A51 = 19372.0 / 6561.0, A52 = -25360.0 / 2187.0, A53 = 64448.0 / 6561.0, A54 = -212.0 / 729.0;
+constexpr double A61 = 9017.0 / 3168.0, A62 = -355.0 / 33.0, A63 = 46732.0 / 5247.0, A64 = 49.0 / 176.0,
+                 A65 = -5103.0 / 18656.0;
+constexpr double A71 = 35.0 / 384.0, A73 = 500.0 / 1113.0, A74 = 125.0 / 192.0, A75 = -2187.0 / 6784.0,
+                 A76 = 11.0 / 84.0;
+constexpr double E1 = 71.0 / 57600.0, E3 = -71.0 / 16695.0, E4 = 71.0 / 1920.0, E5 = -17253.0 / 339200.0,
+                 E6 = 22.0 / 525.0, E7 = -1.0 / 40.0;
+}  // namespace dp
+
+#define SBM_ALL(c, i)                       \
+  _Pragma("unroll") for (int c = 0; c < CPL; ++c) \
+  _Pragma("unroll") for (int i = 0; i < NV; ++i)
+
+// ---------------------------------------------------------------------------
+// "System" policies: what differs between the two mappings
+// ---------------------------------------------------------------------------
+struct SbmLdsParams {  // [param][lane] image in LDS
+  const double* base;
+  __device__ __forceinline__ double operator[](int c) const { return base[c * 64]; }
+};
+
+// one trajectory per wave; lane = column of [y | S]
+template <class M>
+struct SensSystem {
+  static constexpr int NV = M::NV;
+  static constexpr int NCOL = 1 + M::NK;
+  static constexpr int CPL = (NCOL + 63) / 64;
+  static constexpr bool kUniform = true;
+  const double* __restrict__ p;  // wave-uniform -> scalar loads
+  int lane;
+
+  __device__ __forceinline__ void rhs(double t, const double (&z)[CPL][NV], double (&dz)[CPL][NV]) const {
+    double y[NV], f[NV], jy[M::NJY], jp[M::NJP];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) y[i] = sbm_bcast0(z[0][i]);
+    M::eval_jac(t, y, p, f, jy, jp);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) M::apply_col(jy, jp, lane + 64 * c - 1, z[c], dz[c]);
+    const bool state_lane = (lane == 0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dz[0][i] = state_lane ? f[i] : dz[0][i];
+  }
+  // error norm: max over columns of the column's RMS (every column, the state
+  // included, individually meets the tolerance -- the CVODES-style sens. test)
+  __device__ __forceinline__ float norm(const float (&colsum)[CPL]) const {
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) m = sbm_nanmax(m, colsum[c]);
+    // fmaxf drops NaNs: carry them explicitly
+    const float bad = (m != m) ? 1.f : 0.f;
+    const float mx = sbm_wave_max((m != m) ? 0.f : m);
+    const float anybad = sbm_wave_max(bad);
+    return anybad > 0.f ? __builtin_nanf("") : sqrtf(mx * (1.0f / NV));
+  }
+  __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
+};
+
+// one trajectory per lane; state only
+template <class M>
+struct StateSystem {
+  static constexpr int NV = M::NV;
+  static constexpr int CPL = 1;
+  static constexpr bool kUniform = false;
+  SbmLdsParams p;
+
+  __device__ __forceinline__ void rhs(double t, const double (&z)[1][NV], double (&dz)[1][NV]) const {
+    M::eval_f(t, z[0], p, dz[0]);
+  }
+  __device__ __forceinline__ float norm(const float (&colsum)[1]) const { return sqrtf(colsum[0] * (1.0f / NV)); }
+  __device__ __forceinline__ double sum(double v) const { return v; }
+};
+
+// ---------------------------------------------------------------------------
+// per-trajectory driver state shared by both integrators
+// ---------------------------------------------------------------------------
+struct SbmTrajOut {
+  int32_t status;
+  int32_t n_acc;
+  int32_t n_rej;
+};
+
+// Dormand-Prince 5(4) with FSAL, I-controller (safety 0.9, factor in [0.2, 10]),
+// landing exactly on every output time (the reference samples the solution AT
+// grid points, project/utils.py:18-21 -- no dense output, no interpolation).
+// `Store` is called as store(io, z) once per output index.
+template <class Sys, class Store>
+__device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sys::CPL][Sys::NV],
+                                                   const double* __restrict__ t_out, int n_t,
+                                                   const sbm_integrator_opts& o, Store&& store) {
+  constexpr int NV = Sys::NV;
+  constexpr int CPL = Sys::CPL;
+  using namespace dp;
+  const double rtol = o.rtol, atol = o.atol;
+  const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000;
+
+  double k1[CPL][NV], k2[CPL][NV], k3[CPL][NV], k4[CPL][NV], k5[CPL][NV], k6[CPL][NV], zt[CPL][NV];
+  double t = 0.0;
+  SbmTrajOut out{SBM_OK, 0, 0};
+  if (n_t <= 0) return out;
+  const double t_last = t_out[n_t - 1];
+
+  sys.rhs(t, z, k1);
+
+  // ---- initial step (Hairer's hinit) ----
+  double h = o.h0;
+  if (!(h > 0.0)) {
+    double dnf = 0.0, dny = 0.0;
+    SBM_ALL(c, i) {
+      const double sk = atol + rtol * fabs(z[c][i]);
+      const double a = k1[c][i] / sk, b = z[c][i] / sk;
+      dnf = fma(a, a, dnf);
+      dny = fma(b, b, dny);
+    }
+    dnf = sys.sum(dnf);
+    dny = sys.sum(dny);
+    h = (dnf <= 1e-10 || dny <= 1e-10) ? 1e-6 : sqrt(dny / dnf) * 0.01;
+    h = fmin(h, t_last > 0.0 ? t_last : 1.0);
+    SBM_ALL(c, i) zt[c][i] = fma(h, k1[c][i], z[c][i]);
+    sys.rhs(t + h, zt, k2);
+    double der2 = 0.0;
+    SBM_ALL(c, i) {
+      const double sk = atol + rtol * fabs(z[c][i]);
+      const double a = (k2[c][i] - k1[c][i]) / sk;
+      der2 = fma(a, a, der2);
+    }
+    der2 = sqrt(sys.sum(der2)) / h;
+    const double der12 = fmax(fabs(der2), sqrt(dnf));
+    const double h1 = (der12 <= 1e-15) ? fmax(1e-6, fabs(h) * 1e-3) : pow(0.01 / der12, 0.2);
+    h = fmin(fmin(100.0 * h, h1), t_last > 0.0 ? t_last : 1.0);
+    if (!(h > 0.0)) h = 1e-6;
+  }
+
+  int n_try = 0;
+  bool failed = false;
+  for (int io = 0; io < n_t; ++io) {
+    const double target = t_out[io];
+    while (!failed && t < target) {
+      if (n_try >= max_steps) { out.status = SBM_MAX_STEPS; failed = true; break; }
+      ++n_try;
+      // clip to land on the output time
+      double hs = h;
+      bool last = false;
+      if (t + 1.01 * hs >= target) { hs = target - t; last = true; }
+
+      const double ha21 = hs * A21;
+      SBM_ALL(c, i) zt[c][i] = fma(ha21, k1[c][i], z[c][i]);
+      sys.rhs(t + C2 * hs, zt, k2);
+
+      const double ha31 = hs * A31, ha32 = hs * A32;
+      SBM_ALL(c, i) zt[c][i] = fma(ha32, k2[c][i], fma(ha31, k1[c][i], z[c][i]));
+      sys.rhs(t + C3 * hs, zt, k3);
+
+      const double ha41 = hs * A41, ha42 = hs * A42, ha43 = hs * A43;
+      SBM_ALL(c, i) zt[c][i] = fma(ha43, k3[c][i], fma(ha42, k2[c][i], fma(ha41, k1[c][i], z[c][i])));
+      sys.rhs(t + C4 * hs, zt, k4);
+
+      const double ha51 = hs * A51, ha52 = hs * A52, ha53 = hs * A53, ha54 = hs * A54;
+      SBM_ALL(c, i)
+      zt[c][i] = fma(ha54, k4[c][i], fma(ha53, k3[c][i], fma(ha52, k2[c][i], fma(ha51, k1[c][i], z[c][i]))));
+      sys.rhs(t + C5 * hs, zt, k5);
+
+      const double ha61 = hs * A61, ha62 = hs * A62, ha63 = hs * A63, ha64 = hs * A64, ha65 = hs * A65;
+      SBM_ALL(c, i)
+      zt[c][i] = fma(ha65, k5[c][i],
+                     fma(ha64, k4[c][i], fma(ha63, k3[c][i], fma(ha62, k2[c][i], fma(ha61, k1[c][i], z[c][i])))));
+      sys.rhs(t + hs, zt, k6);
+
+      // 5th-order solution into zt; k2 is dead from here on and receives k7 = f(z_new) (FSAL)
+      const double ha71 = hs * A71, ha73 = hs * A73, ha74 = hs * A74, ha75 = hs * A75, ha76 = hs * A76;
+      SBM_ALL(c, i)
+      zt[c][i] = fma(ha76, k6[c][i],
+                     fma(ha75, k5[c][i], fma(ha74, k4[c][i], fma(ha73, k3[c][i], fma(ha71, k1[c][i], z[c][i])))));
+      sys.rhs(t + hs, zt, k2);
+
+      // embedded error estimate; ratios and norm in f32 (they only steer the controller)
+      const double he1 = hs * E1, he3 = hs * E3, he4 = hs * E4, he5 = hs * E5, he6 = hs * E6, he7 = hs * E7;
+      float colsum[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const double e = fma(he7, k2[c][i],
+                               fma(he6, k6[c][i], fma(he5, k5[c][i], fma(he4, k4[c][i], fma(he3, k3[c][i], he1 * k1[c][i])))));
+          const double sc = fma(rtol, fmax(fabs(z[c][i]), fabs(zt[c][i])), atol);
+          const float r = (float)e * __builtin_amdgcn_rcpf((float)sc);
+          acc = fmaf(r, r, acc);
+        }
+        colsum[c] = acc;
+      }
+      const float err = sys.norm(colsum);
+
+      const bool finite = (err == err) && (err < 3.0e38f);
+      const bool accept = finite && (err <= 1.0f);
+      float fac;
+      if (!finite) {
+        fac = 0.2f;
+      } else {
+        // 0.9 * err^(-1/5), clipped
+        fac = 0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(fmaxf(err, 1e-30f)));
+        fac = fminf(10.f, fmaxf(0.2f, fac));
+      }
+      if (accept) {
+        ++out.n_acc;
+        t = last ? target : t + hs;
+        SBM_ALL(c, i) { z[c][i] = zt[c][i]; k1[c][i] = k2[c][i]; }
+        const double hn = hs * (double)fac;
+        // a step clipped to hit an output time says nothing against the unclipped proposal
+        h = last ? fmax(hn, h) : hn;
+      } else {
+        ++out.n_rej;
+        h = hs * (double)fminf(fac, 1.0f);
+        if (!(h > 1e-14 * fmax(fabs(t), 1e-3))) {
+          out.status = finite ? SBM_STEP_UNDERFLOW : SBM_NON_FINITE;
+          failed = true;
+        }
+      }
+    }
+    if (failed) {
+      SBM_ALL(c, i) z[c][i] = __builtin_nan("");
+    }
+    store(io, z);
+  }
+  return out;
+}
+
+// classic RK4, fixed step: every output interval is cut into ceil(dt / h0) equal steps
+template <class Sys, class Store>
+__device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::CPL][Sys::NV],
+                                               const double* __restrict__ t_out, int n_t,
+                                               const sbm_integrator_opts& o, Store&& store) {
+  constexpr int NV = Sys::NV;
+  constexpr int CPL = Sys::CPL;
+  double k[CPL][NV], acc[CPL][NV], zt[CPL][NV];
+  SbmTrajOut out{SBM_OK, 0, 0};
+  const double h0 = o.h0;
+  const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000000;
+  double t = 0.0;
+  bool failed = !(h0 > 0.0);
+  if (failed) out.status = SBM_STEP_UNDERFLOW;
+  for (int io = 0; io < n_t; ++io) {
+    const double target = t_out[io];
+    const double dt = target - t;
+    if (!failed && dt > 0.0) {
+      const double nd = ceil(dt / h0 - 1e-9);
+      int ns = nd < 1.0 ? 1 : (nd > 2.0e9 ? 2000000000 : (int)nd);
+      if (out.n_acc + ns > max_steps) { out.status = SBM_MAX_STEPS; failed = true; }
+      if (!failed) {
+        const double hs = dt / ns, hh = 0.5 * hs, h6 = hs * (1.0 / 6.0);
+        const double t0 = t;
+        for (int s = 0; s < ns; ++s) {
+          const double ts = fma((double)s, hs, t0);
+          sys.rhs(ts, z, k);
+          SBM_ALL(c, i) { acc[c][i] = k[c][i]; zt[c][i] = fma(hh, k[c][i], z[c][i]); }
+          sys.rhs(ts + hh, zt, k);
+          SBM_ALL(c, i) { acc[c][i] = fma(2.0, k[c][i], acc[c][i]); zt[c][i] = fma(hh, k[c][i], z[c][i]); }
+          sys.rhs(ts + hh, zt, k);
+          SBM_ALL(c, i) { acc[c][i] = fma(2.0, k[c][i], acc[c][i]); zt[c][i] = fma(hs, k[c][i], z[c][i]); }
+          sys.rhs(ts + hs, zt, k);
+          SBM_ALL(c, i) z[c][i] = fma(h6, acc[c][i] + k[c][i], z[c][i]);
+        }
+        out.n_acc += ns;
+        t = target;
+      }
+    }
+    if (failed) {
+      SBM_ALL(c, i) z[c][i] = __builtin_nan("");
+    }
+    store(io, z);
+  }
+  // RK4 has no error estimate: flag non-finite end states
+  bool bad = false;
+  SBM_ALL(c, i) bad = bad || !(z[c][i] == z[c][i]);
+  if (!failed && bad) out.status = SBM_NON_FINITE;
+  return out;
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+// Sensitivity kernel.  grid = n_traj blocks of one wave; at ~1 wave per SIMD
+// (the stage vectors fill most of the 512-VGPR budget) a CU holds 4 trajectories,
+// the chip 1024, so a 4096-vector ensemble is 4 waves of work per SIMD.
+template <class M, int METHOD>
+__global__ void __launch_bounds__(64) sbm_sens_kernel(sbm_kernel_args a) {
+  using Sys = SensSystem<M>;
+  constexpr int NV = Sys::NV;
+  constexpr int CPL = Sys::CPL;
+  constexpr int NK = M::NK;
+  const int traj = blockIdx.x;  // wave-uniform
+  const int lane = threadIdx.x;
+  if (traj >= a.n_traj) return;
+
+  Sys sys{a.P + (size_t)traj * M::NP, lane};
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+
+  double z[CPL][NV];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int col = lane + 64 * c;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double v = 0.0;
+      if (col == 0) {
+        if (a.y0) v = a.y0[i];
+      } else if (col <= NK) {
+        if (a.s0) v = a.s0[i * NK + (col - 1)];
+      }
+      z[c][i] = v;
+    }
+  }
+
+  double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
+  double* St = a.S ? a.S + (size_t)traj * a.n_t * NV * NK : nullptr;
+  auto store = [&](int io, const double (&zz)[CPL][NV]) {
+    if (Yt && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) Yt[(size_t)io * NV + i] = zz[0][i];
+    }
+    if (St) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int scol = lane + 64 * c - 1;
+        if (scol >= 0 && scol < NK) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + scol] = zz[c][i];
+        }
+      }
+    }
+  };
+
+  SbmTrajOut r;
+  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
+  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+
+  if (lane == 0) {
+    if (a.status) a.status[traj] = r.status;
+    if (a.n_steps) a.n_steps[traj] = r.n_acc;
+    if (a.n_reject) a.n_reject[traj] = r.n_rej;
+  }
+}
+
+// State-only kernel.  One trajectory per lane, 64 per block.
+template <class M, int METHOD>
+__global__ void __launch_bounds__(64) sbm_state_kernel(sbm_kernel_args a) {
+  using Sys = StateSystem<M>;
+  constexpr int NV = Sys::NV;
+  constexpr int NP = M::NP;
+  __shared__ double p_lds[NP * 64];
+  const int lane = threadIdx.x;
+  const int traj0 = blockIdx.x * 64;
+  const int traj = traj0 + lane;
+  const int n_here = min(64, a.n_traj - traj0);
+
+  // coalesced read of the block's 64 x NP parameter slab, transposed into LDS
+  const double* Pb = a.P + (size_t)traj0 * NP;
+  for (int e = lane; e < n_here * NP; e += 64) {
+    const int tl = e / NP, c = e - tl * NP;
+    p_lds[c * 64 + tl] = Pb[e];
+  }
+  __syncthreads();
+  if (traj >= a.n_traj) return;
+
+  Sys sys{SbmLdsParams{p_lds + lane}};
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+
+  double z[1][NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) z[0][i] = a.y0 ? a.y0[i] : 0.0;
+
+  double* Yt = a.Y + (size_t)traj * a.n_t * NV;
+  auto store = [&](int io, const double (&zz)[1][NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) Yt[(size_t)io * NV + i] = zz[0][i];
+  };
+
+  SbmTrajOut r;
+  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
+  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+
+  if (a.status) a.status[traj] = r.status;
+  if (a.n_steps) a.n_steps[traj] = r.n_acc;
+  if (a.n_reject) a.n_reject[traj] = r.n_rej;
+}
+
+// ---------------------------------------------------------------------------
+// host-side launcher used by sbm_plugin_main.hip
+// ---------------------------------------------------------------------------
+template <class M>
+static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t stream) {
+  const sbm_kernel_args a = *args;
+  if (a.n_traj <= 0) return (int)hipSuccess;
+  if (kind == SBM_KIND_SENS) {
+    dim3 grid(a.n_traj), block(64);
+    if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+  } else {
+    dim3 grid((a.n_traj + 63) / 64), block(64);
+    if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_state_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((sbm_state_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,137 @@
+"""Model definitions used by the tests and the benchmark.
+
+``simple`` and ``michaelis_menten`` restate, in this package's model-text
+format, the two known-answer systems of the reference's tests
+(math of tests/test_utils/simple_model.py:6-23 and
+michelis_menten_model.py:10-33; parameter order of jittable_model.py:1 and
+jittable_mm_model.py:1).  ``cascade20`` and ``stiff50`` are this build's
+synthetic benchmark networks.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import sympy
+from sympy import Symbol
+
+from .symbolic.emit import ModelSpec
+
+SIMPLE_MODEL_TEXT = """
+#*! Parameters Start
+    k_deg = p[0]
+    k_synt = p[1]
+#*! Parameters End
+
+#*! Variables Start
+    _y = y[0]
+#*! Variables End
+
+#*! Differential Equations Start
+    d__y = k_synt - k_deg * _y
+#*! Differential Equations End
+"""
+
+MICHAELIS_MENTEN_TEXT = """
+#*! Parameters Start
+    vmax = p[0]
+    km = p[1]
+    k_synt_s = p[2]
+    k_deg_s = p[3]
+    k_deg_p = p[4]
+#*! Parameters End
+
+#*! Variables Start
+    _s = y[0]
+    _p = y[1]
+#*! Variables End
+
+#*! Rate Laws Start
+    v_conv = vmax * (_s / (km + _s))
+#*! Rate Laws End
+
+#*! Differential Equations Start
+    d__s = k_synt_s - v_conv - k_deg_s * _s
+    d__p = v_conv - k_deg_p * _p
+#*! Differential Equations End
+"""
+
+
+def simple_spec():
+    return ModelSpec.from_text(SIMPLE_MODEL_TEXT, name='simple')
+
+
+def michaelis_menten_spec():
+    return ModelSpec.from_text(MICHAELIS_MENTEN_TEXT, name='michaelis_menten')
+
+
+# ----------------------------------------------------------------------------
+# cascade20: 20 species / 40 parameters, negative feedback + saturating cascade
+# ----------------------------------------------------------------------------
+CASCADE_N = 20
+CASCADE_K_FEEDBACK = 1.0
+
+
+def cascade_spec(n=CASCADE_N, name=None):
+    """x_0' = k_0/(1 + x_{n-1}/K) - d_0 x_0 ;  x_i' = k_i x_{i-1}/(1 + x_{i-1}) - d_i x_i.
+
+    Parameter order: k_0..k_{n-1}, d_0..d_{n-1}.  K = 1 is a literal constant.
+    """
+    xs = [Symbol('x%d' % i) for i in range(n)]
+    ks = [Symbol('k%d' % i) for i in range(n)]
+    ds = [Symbol('d%d' % i) for i in range(n)]
+    eq = OrderedDict()
+    eq['x0'] = ks[0] / (1 + xs[n - 1] / sympy.Float(CASCADE_K_FEEDBACK)) - ds[0] * xs[0]
+    for i in range(1, n):
+        eq['x%d' % i] = ks[i] * xs[i - 1] / (1 + xs[i - 1]) - ds[i] * xs[i]
+    # Float(1.0) factors print as 1.0*..., fold them
+    eq = OrderedDict((v, sympy.nsimplify(e, rational=True)) for v, e in eq.items())
+    return ModelSpec(name=name or ('cascade%d' % n), variables=[str(x) for x in xs],
+                     params=[str(k) for k in ks] + [str(d) for d in ds], equations=eq)
+
+
+def cascade_nominal_params(n=CASCADE_N):
+    """k_i = 1, d_i = 0.1 (1 + i/n)."""
+    k = np.ones(n)
+    d = 0.1 * (1.0 + np.arange(n) / float(n))
+    return np.concatenate([k, d])
+
+
+def cascade_ensemble(n_vectors=4096, n=CASCADE_N, seed=20261003, spread=0.5):
+    """theta_v = log(p_nom) + spread * z, z ~ N(0, I); returns (theta, p = exp(theta)), row-major (V, 2n)."""
+    rng = np.random.default_rng(seed)
+    theta = np.log(cascade_nominal_params(n))[None, :] + spread * rng.standard_normal((n_vectors, 2 * n))
+    return theta, np.exp(theta)
+
+
+CASCADE_T_END = 100.0
+CASCADE_MEASURE_TIMES = np.linspace(6.25, 100.0, 16)
+CASCADE_MEASURED_SPECIES = (4, 9, 14, 19)
+
+
+# ----------------------------------------------------------------------------
+# stiff50: 50-state signalling cascade with rate constants spanning 1e6
+# ----------------------------------------------------------------------------
+def stiff_spec(n=50, name=None):
+    """Linear-activation cascade with Michaelis-Menten deactivation.
+
+    x_0' = a_0 (1 - x_0) - b_0 x_0/(0.1 + x_0);  x_i' = a_i x_{i-1} (1 - x_i) - b_i x_i/(0.1 + x_i).
+    Parameters a_0..a_{n-1} (activation), b_0.. (deactivation): 2n in total; the
+    nominal a_i span six decades, which is what makes the system stiff.
+    """
+    xs = [Symbol('x%d' % i) for i in range(n)]
+    a = [Symbol('a%d' % i) for i in range(n)]
+    b = [Symbol('b%d' % i) for i in range(n)]
+    tenth = sympy.Rational(1, 10)
+    eq = OrderedDict()
+    eq['x0'] = a[0] * (1 - xs[0]) - b[0] * xs[0] / (tenth + xs[0])
+    for i in range(1, n):
+        eq['x%d' % i] = a[i] * xs[i - 1] * (1 - xs[i]) - b[i] * xs[i] / (tenth + xs[i])
+    return ModelSpec(name=name or ('stiff%d' % n), variables=[str(x) for x in xs],
+                     params=[str(s) for s in a] + [str(s) for s in b], equations=eq)
+
+
+def stiff_nominal_params(n=50):
+    a = 10.0 ** np.linspace(-2.0, 4.0, n)
+    b = 0.5 * np.ones(n)
+    return np.concatenate([a, b])

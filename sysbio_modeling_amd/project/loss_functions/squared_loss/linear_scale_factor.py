@@ -1,0 +1,36 @@
+"""Linear scale factor B = sum(s d / sigma^2) / sum(s^2 / sigma^2).
+
+The arithmetic of the reference's ``update_sf`` / ``update_sf_gradient``
+(project/loss_functions/squared_loss/linear_scale_factor.py:27-42) runs on the
+device inside csrc/sbm_core.hip::k_assemble; this object only carries the latest
+values back to the caller (``Project.scale_factors[measure].sf``).
+"""
+import numpy as np
+
+from ..abstract_scale_factor import ScaleFactorABC
+
+
+class LinearScaleFactor(ScaleFactorABC):
+    def __init__(self, log_prior=None, log_prior_sigma=None):
+        super(LinearScaleFactor, self).__init__(log_prior, log_prior_sigma)
+        self._sf = 1.0
+
+    @property
+    def sf(self):
+        return self._sf
+
+    @property
+    def gradient(self):
+        return None if self._sf_gradient is None else np.array(self._sf_gradient, copy=True)
+
+    def calc_sf_prior_residual(self):
+        """(log B - log_prior) / sigma  (reference :55-61)."""
+        if self.log_prior is None:
+            return None
+        return (np.log(self._sf) - self.log_prior) / self.log_prior_sigma
+
+    def calc_sf_prior_gradient(self):
+        """d log B / d theta = (dB/dtheta) / B  (reference :44-53)."""
+        if self.log_prior is None or self._sf_gradient is None:
+            return None
+        return self._sf_gradient / self._sf

@@ -1,0 +1,152 @@
+"""Symbolic front end: model text -> derived equations -> generated sources.
+
+The reference's ``symbolic`` package exposes (through its tests and CLI) a
+``make_jit_model`` facade that does not exist in its tree
+(symbolic/__init__.py is empty; tests/test_sympy_tools.py:11).  This package
+provides the working equivalent: ``make_ode_model`` returns a
+:class:`GeneratedModel` whose ``model`` / ``sens_model`` callables follow the
+reference callback contract and whose HIP plugin runs the same equations on
+the GPU.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+from .sympy_tools import (parse_model_file, process_model_dict, derive_sparse_jacobians,
+                          _derive_sensitivity_equations, _derive_jacobian_equations)
+from .emit import ModelSpec, Derived, emit_python, emit_c, emit_hip
+
+__all__ = ['parse_model_file', 'process_model_dict', 'make_ode_model', 'make_jit_model',
+           'GeneratedModel', 'ModelSpec', 'generated_model_of']
+
+
+class GeneratedModel(object):
+    """All artefacts generated from one :class:`ModelSpec`.
+
+    Attributes
+    ----------
+    model, sens_model : callables ``f(y, t, yout, p) -> None`` (CPU; they are what
+        the oracle integrates with SciPy and what a reference ``OdeModel`` accepts)
+    n_vars, param_order, sens_params : layout of y / p / sensitivity columns
+    python_source, c_source, hip_source : generated text
+    """
+
+    def __init__(self, spec: ModelSpec, header_path=None):
+        self.spec = spec
+        self.name = spec.name
+        self.derived = Derived(spec)
+        self.python_source = emit_python(spec, self.derived)
+        self.c_source = emit_c(spec, self.derived)
+        self.hip_source = emit_hip(spec, self.derived)
+        self.n_vars = spec.n_vars
+        self.param_order = list(spec.params)
+        self.sens_params = list(spec.sens_params)
+        self.n_sens = spec.n_sens
+        self._header_path = header_path
+        ns = {}
+        exec(compile(self.python_source, '<generated %s>' % spec.name, 'exec'), ns)
+        self.model = ns['model']
+        self.sens_model = ns['sens_model']
+        # tag the callables so that OdeModel can find the GPU plugin behind them
+        self.model._sbm_generated = self
+        self.sens_model._sbm_generated = self
+        self._plugin = None
+        self._c_lib = None
+
+    # -- GPU plugin ---------------------------------------------------------
+    def header_path(self):
+        from .. import build
+        if self._header_path and os.path.exists(self._header_path):
+            with open(self._header_path) as fh:
+                if fh.read() == self.hip_source:
+                    return self._header_path
+        path, _ = build.write_generated_header(self.name, self.hip_source)
+        return path
+
+    def plugin_path(self, build_if_missing=True):
+        """Path of the compiled plugin; built with hipcc on first use."""
+        from .. import build
+        if self._plugin and os.path.exists(self._plugin):
+            return self._plugin
+        header = self.header_path()
+        tag = self.name if header.startswith(build.MODELS_DIR) else os.path.splitext(os.path.basename(header))[0]
+        out = build.plugin_path(tag)
+        if build_if_missing:
+            out = build.build_plugin(tag, header)
+        elif not os.path.exists(out):
+            raise build.BuildError("model plugin %s has not been built" % out)
+        self._plugin = out
+        return out
+
+    # -- compiled C RHS (oracle / CPU baseline only) -------------------------
+    def c_library(self):
+        import ctypes
+        from .. import build
+        if self._c_lib is None:
+            so = build.build_c_rhs(self.name, self.c_source)
+            lib = ctypes.CDLL(so)
+            dp = ctypes.POINTER(ctypes.c_double)
+            for fn in (lib.sbm_rhs, lib.sbm_sens_rhs):
+                fn.argtypes = [dp, ctypes.c_double, dp, dp]
+                fn.restype = None
+            self._c_lib = lib
+        return self._c_lib
+
+
+def make_ode_model(model, name='Model', fixed_params=None, output_fh=None):
+    """Model text / function / file / dict / ModelSpec -> :class:`GeneratedModel`.
+
+    Counterpart of the reference's parse -> process -> make_ode_model chain
+    (symbolic/sympy_tools.py:272,325,162).  ``output_fh`` receives the generated
+    Python module text, as the reference's ``output_fh`` does (:202-204).
+    """
+    if isinstance(model, ModelSpec):
+        spec = model
+    elif isinstance(model, dict):
+        spec = ModelSpec.from_model_dict(model, name=name)
+    else:
+        spec = ModelSpec.from_text(model, name=name, fixed_params=fixed_params)
+    gm = GeneratedModel(spec)
+    if output_fh is not None:
+        output_fh.write(gm.python_source)
+    return gm
+
+
+def make_jit_model(model_fh, output_fh=None, calculate_sensitivities=True, name='Model', fixed_params=None):
+    """Name the reference's tests and CLI import (tests/test_sympy_tools.py:11,
+    tests/test_utils/michelis_menten_model.py:55-63)."""
+    gm = make_ode_model(model_fh, name=name, fixed_params=fixed_params, output_fh=output_fh)
+    return gm.sens_model if calculate_sensitivities else gm.model
+
+
+def generated_model_of(fn):
+    """The GeneratedModel behind a generated callable, or None."""
+    return getattr(fn, '_sbm_generated', None)
+
+
+# ---------------------------------------------------------------------------
+# zoo: models whose generated headers are committed under csrc/models/
+# ---------------------------------------------------------------------------
+_ZOO_CACHE = {}
+
+
+def zoo_model(name):
+    """'simple', 'michaelis_menten', 'cascade20', 'stiff50' -> GeneratedModel (cached)."""
+    from .. import models_zoo, build
+    if name in _ZOO_CACHE:
+        return _ZOO_CACHE[name]
+    makers = OrderedDict([
+        ('simple', models_zoo.simple_spec),
+        ('michaelis_menten', models_zoo.michaelis_menten_spec),
+        ('cascade20', models_zoo.cascade_spec),
+        ('stiff50', models_zoo.stiff_spec),
+    ])
+    if name not in makers:
+        raise KeyError("unknown zoo model %r (have %s)" % (name, ", ".join(makers)))
+    gm = GeneratedModel(makers[name](), header_path=os.path.join(build.MODELS_DIR, name + '.hpp'))
+    _ZOO_CACHE[name] = gm
+    return gm
+
+
+ZOO_NAMES = ('simple', 'michaelis_menten', 'cascade20')

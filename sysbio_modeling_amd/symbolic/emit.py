@@ -1,0 +1,362 @@
+"""Source emitters: one symbolic model -> Python, C and HIP right-hand sides.
+
+Replaces the reference's Python-only emitter (symbolic/sympy_tools.py:162-216
+``make_ode_model``: one ``yout[i] = (expr)`` line per equation, ``exec``-ed).
+All three targets are printed from the SAME common-subexpression-eliminated
+expression set so that the GPU kernels, the C oracle RHS and the Python
+callables (reference callback contract ``f(y, t, yout, p) -> None``,
+tests/test_utils/sens_jittable_model.py:1-38) agree term by term.
+
+Layout contract (reference symbolic/sympy_tools.py:130-146,185-195):
+``yout[0:n]`` state derivatives, ``yout[n + i*k + j]`` = d/dt (d y_i / d p_j)
+with j running over the non-fixed parameters in ``param_order``.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass, field
+
+import sympy
+from sympy import Symbol, cse
+from sympy.printing.c import C99CodePrinter
+
+from . import sympy_tools
+
+
+_RCP = sympy.Function('SBM_RCP')
+
+
+def _canon_rcp(expr):
+    """b**(-n) -> SBM_RCP(b)**n (integer n) so that CSE shares ONE reciprocal per
+    distinct denominator; reciprocals dominate the cost of rate-law right-hand sides."""
+    def is_neg_pow(e):
+        return e.is_Pow and e.exp.is_number and e.exp.is_negative
+
+    def repl(e):
+        if e.exp.is_Integer:
+            return sympy.Pow(_RCP(e.base), -e.exp)
+        return _RCP(sympy.Pow(e.base, -e.exp))
+    return expr.replace(is_neg_pow, repl)
+
+
+# ----------------------------------------------------------------------------
+# model specification
+# ----------------------------------------------------------------------------
+@dataclass
+class ModelSpec:
+    """A model ready for emission.
+
+    variables / params are ordered name lists (the order IS the y / p layout,
+    reference ``ordered_params`` / header order symbolic/sympy_tools.py:100-111);
+    ``fixed`` names parameters without sensitivity columns; ``equations`` maps
+    each variable to d(var)/dt as a SymPy expression in those names and ``t``.
+    """
+    name: str
+    variables: list
+    params: list
+    equations: OrderedDict
+    fixed: list = field(default_factory=list)
+
+    @property
+    def n_vars(self):
+        return len(self.variables)
+
+    @property
+    def n_params(self):
+        return len(self.params)
+
+    @property
+    def sens_params(self):
+        return [p for p in self.params if p not in self.fixed]
+
+    @property
+    def n_sens(self):
+        return len(self.sens_params)
+
+    @classmethod
+    def from_model_dict(cls, model_dict, name='Model'):
+        if 'Expanded Equations' not in model_dict:
+            sympy_tools.process_model_dict(model_dict)
+        params = model_dict['Parameters']
+        fixed = [p for p in params if params[p] == 'fixed']
+        return cls(name=name, variables=list(model_dict['Variables'].keys()),
+                   params=list(params.keys()),
+                   equations=OrderedDict(model_dict['Expanded Equations']), fixed=fixed)
+
+    @classmethod
+    def from_text(cls, model, name='Model', fixed_params=None):
+        md = sympy_tools.parse_model_file(model)
+        sympy_tools.process_model_dict(md, fixed_params=fixed_params,
+                                       calculate_model_sensitivities=False)
+        return cls.from_model_dict(md, name=name)
+
+
+# ----------------------------------------------------------------------------
+# derived form shared by all emitters
+# ----------------------------------------------------------------------------
+class Derived:
+    """f, nnz(J_y), nnz(J_p) after joint CSE."""
+
+    def __init__(self, spec: ModelSpec):
+        self.spec = spec
+        params = OrderedDict((p, 'fixed' if p in spec.fixed else Symbol(p)) for p in spec.params)
+        jy, jp = sympy_tools.derive_sparse_jacobians(spec.equations, params)
+        self.jy = jy  # (row, col, expr)
+        self.jp = jp  # (row, sens col, expr)
+        f_exprs = [_canon_rcp(sympy.sympify(spec.equations[v])) for v in spec.variables]
+        all_exprs = f_exprs + [_canon_rcp(e) for _, _, e in jy] + [_canon_rcp(e) for _, _, e in jp]
+        # joint CSE: subexpressions of f are shared with its derivatives
+        self.repl_all, red_all = cse(all_exprs, symbols=sympy.numbered_symbols('x_'),
+                                     optimizations='basic')
+        n = len(f_exprs)
+        self.f_red = red_all[:n]
+        self.jy_red = red_all[n:n + len(jy)]
+        self.jp_red = red_all[n + len(jy):]
+        # state-only form
+        self.repl_f, self.f_only = cse(f_exprs, symbols=sympy.numbered_symbols('x_'),
+                                       optimizations='basic')
+        # per row pattern
+        self.jy_rows = [[] for _ in range(spec.n_vars)]
+        for e, (r, c, _) in enumerate(jy):
+            self.jy_rows[r].append((e, c))
+        self.jp_rows = [[] for _ in range(spec.n_vars)]
+        for e, (r, c, _) in enumerate(jp):
+            self.jp_rows[r].append((e, c))
+
+
+class _ExprPrinter(C99CodePrinter):
+    """C-family expression printer with explicit reciprocals.
+
+    ``rcp`` is a format string for 1/x: the HIP target maps it to the device
+    fast reciprocal (v_rcp_f64 + two Newton steps), C and Python to ``1.0/x``.
+    """
+
+    def __init__(self, symbol_map, rcp="(1.0/(%s))", lang='c'):
+        super().__init__({'strict': False} if 'strict' in C99CodePrinter._default_settings else {})
+        self._smap = symbol_map
+        self._rcp = rcp
+        self._lang = lang
+
+    def doprint(self, expr, assign_to=None):
+        # x**(-n) -> RCP(x**n) BEFORE printing: the stock Mul printer would otherwise
+        # collect negative powers into an a/b division
+        expr = sympy.sympify(expr).replace(
+            lambda e: e.is_Pow and e.exp.is_number and e.exp.is_negative,
+            lambda e: _RCP(sympy.Pow(e.base, -e.exp)))
+        return super().doprint(expr, assign_to)
+
+    def _print_Function(self, expr):
+        if expr.func == _RCP:
+            return self._rcp % self._print(expr.args[0])
+        return super()._print_Function(expr)
+
+    def _print_Symbol(self, expr):
+        return self._smap.get(expr.name, expr.name)
+
+    def _print_Rational(self, expr):
+        return "(%d.0/%d.0)" % (expr.p, expr.q)
+
+    def _print_Integer(self, expr):
+        return "%d.0" % int(expr.p) if int(expr.p) >= 0 else "(%d.0)" % int(expr.p)
+
+    def _mulpow(self, base, n):
+        b = self._print(base)
+        if not (base.is_Symbol or base.is_Number):
+            b = "(%s)" % b
+        return "(" + "*".join([b] * n) + ")"
+
+    def _print_Pow(self, expr):
+        base, exp = expr.as_base_exp()
+        if exp.is_Integer:
+            n = int(exp)
+            if 1 <= n <= 4:
+                return self._mulpow(base, n)
+            if -4 <= n <= -1:
+                inner = self._print(base) if n == -1 else self._mulpow(base, -n)
+                return self._rcp % inner
+        if exp == sympy.Rational(1, 2):
+            return "sqrt(%s)" % self._print(base)
+        if exp == sympy.Rational(-1, 2):
+            return self._rcp % ("sqrt(%s)" % self._print(base))
+        return "pow(%s, %s)" % (self._print(base), self._print(exp))
+
+
+def _symbol_map(spec, y_fmt="y[%d]", p_fmt="p[%d]"):
+    m = {}
+    for i, v in enumerate(spec.variables):
+        m[v] = y_fmt % i
+    for i, p in enumerate(spec.params):
+        m[p] = p_fmt % i
+    m['t'] = 't'
+    return m
+
+
+def _fmt_header(spec, comment):
+    c = comment
+    lines = [
+        "%s generated by sysbio_modeling_amd.symbolic.emit -- do not edit" % c,
+        "%s model '%s': %d states, %d parameters (%d with sensitivities)"
+        % (c, spec.name, spec.n_vars, spec.n_params, spec.n_sens),
+        "%s states: %s" % (c, ", ".join(spec.variables)),
+        "%s params: %s" % (c, ", ".join(spec.params)),
+    ]
+    if spec.fixed:
+        lines.append("%s fixed : %s" % (c, ", ".join(spec.fixed)))
+    return lines
+
+
+# ----------------------------------------------------------------------------
+# Python
+# ----------------------------------------------------------------------------
+def emit_python(spec: ModelSpec, derived: Derived = None) -> str:
+    """Python module source: ``ordered_params``, ``n_vars``, ``model``, ``sens_model``.
+
+    Same callback contract and yout layout as the reference fixtures
+    (tests/test_utils/jittable_model.py:5-26, sens_jittable_model.py:1-38).
+    """
+    d = derived or Derived(spec)
+    n, k = spec.n_vars, spec.n_sens
+    pr = _ExprPrinter(_symbol_map(spec), rcp="(1.0/(%s))", lang='py')
+    pad = "    "
+    L = _fmt_header(spec, "#")
+    L += ["from math import exp, log, sqrt, pow, sin, cos, tanh", "",
+          "ordered_params = [%s]" % ", ".join("'%s'" % p for p in spec.params),
+          "sens_params = [%s]" % ", ".join("'%s'" % p for p in spec.sens_params),
+          "n_vars = %d" % n, "n_sens = %d" % k, "", ""]
+    L += ["def model(y, t, yout, p):"]
+    for s, e in d.repl_f:
+        L.append(pad + "%s = %s" % (s, pr.doprint(e)))
+    for i, e in enumerate(d.f_only):
+        L.append(pad + "yout[%d] = (%s)" % (i, pr.doprint(e)))
+    L += ["", "", "def sens_model(y, t, yout, p):"]
+    for s, e in d.repl_all:
+        L.append(pad + "%s = %s" % (s, pr.doprint(e)))
+    for i, e in enumerate(d.f_red):
+        L.append(pad + "yout[%d] = (%s)" % (i, pr.doprint(e)))
+    for e_idx, e in enumerate(d.jy_red):
+        L.append(pad + "jy_%d = %s" % (e_idx, pr.doprint(e)))
+    for e_idx, e in enumerate(d.jp_red):
+        L.append(pad + "jp_%d = %s" % (e_idx, pr.doprint(e)))
+    for i in range(n):
+        for j in range(k):
+            terms = ["jy_%d*y[%d]" % (e_idx, n + c * k + j) for e_idx, c in d.jy_rows[i]]
+            terms += ["jp_%d" % e_idx for e_idx, c in d.jp_rows[i] if c == j]
+            L.append(pad + "yout[%d] = (%s)" % (n + i * k + j, " + ".join(terms) if terms else "0.0"))
+    L.append("")
+    return "\n".join(L)
+
+
+# ----------------------------------------------------------------------------
+# C (oracle RHS / CPU baseline RHS; plays the role numba plays for the reference)
+# ----------------------------------------------------------------------------
+def emit_c(spec: ModelSpec, derived: Derived = None) -> str:
+    d = derived or Derived(spec)
+    n, k = spec.n_vars, spec.n_sens
+    pr = _ExprPrinter(_symbol_map(spec), rcp="(1.0/(%s))", lang='c')
+    L = _fmt_header(spec, "//")
+    L += ["#include <math.h>", "",
+          "int sbm_n_vars(void) { return %d; }" % n,
+          "int sbm_n_params(void) { return %d; }" % spec.n_params,
+          "int sbm_n_sens(void) { return %d; }" % k, ""]
+    L += ["void sbm_rhs(const double* y, double t, double* yout, const double* p) {", "  (void)t;"]
+    for s, e in d.repl_f:
+        L.append("  const double %s = %s;" % (s, pr.doprint(e)))
+    for i, e in enumerate(d.f_only):
+        L.append("  yout[%d] = %s;" % (i, pr.doprint(e)))
+    L += ["}", ""]
+    nnz_y, nnz_p = max(len(d.jy), 1), max(len(d.jp), 1)
+    L += ["static const int JY_ROW[%d] = {%s};" % (nnz_y, ", ".join(str(r) for r, _, _ in d.jy) or "0"),
+          "static const int JY_COL[%d] = {%s};" % (nnz_y, ", ".join(str(c) for _, c, _ in d.jy) or "0"),
+          "static const int JP_ROW[%d] = {%s};" % (nnz_p, ", ".join(str(r) for r, _, _ in d.jp) or "0"),
+          "static const int JP_COL[%d] = {%s};" % (nnz_p, ", ".join(str(c) for _, c, _ in d.jp) or "0"), ""]
+    L += ["// augmented system: yout[n + i*k + j] = J_p[i][j] + sum_m J_y[i][m] * y[n + m*k + j]",
+          "void sbm_sens_rhs(const double* y, double t, double* yout, const double* p) {", "  (void)t;",
+          "  enum { N = %d, K = %d, NNZ_Y = %d, NNZ_P = %d };" % (n, k, len(d.jy), len(d.jp)),
+          "  double jy[%d], jp[%d];" % (nnz_y, nnz_p)]
+    for s, e in d.repl_all:
+        L.append("  const double %s = %s;" % (s, pr.doprint(e)))
+    for i, e in enumerate(d.f_red):
+        L.append("  yout[%d] = %s;" % (i, pr.doprint(e)))
+    for e_idx, e in enumerate(d.jy_red):
+        L.append("  jy[%d] = %s;" % (e_idx, pr.doprint(e)))
+    for e_idx, e in enumerate(d.jp_red):
+        L.append("  jp[%d] = %s;" % (e_idx, pr.doprint(e)))
+    L += ["  for (int i = N; i < N + N * K; ++i) yout[i] = 0.0;",
+          "  for (int e = 0; e < NNZ_Y; ++e) {",
+          "    const double a = jy[e]; const double* src = y + N + JY_COL[e] * K; double* dst = yout + N + JY_ROW[e] * K;",
+          "    for (int j = 0; j < K; ++j) dst[j] += a * src[j];",
+          "  }",
+          "  for (int e = 0; e < NNZ_P; ++e) yout[N + JP_ROW[e] * K + JP_COL[e]] += jp[e];",
+          "}", ""]
+    return "\n".join(L)
+
+
+# ----------------------------------------------------------------------------
+# HIP device struct
+# ----------------------------------------------------------------------------
+def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
+    """Header defining ``struct SbmModel`` consumed by csrc/sbm_integrators.hpp.
+
+    ``eval_f``   : state RHS only (state-only kernels, one trajectory per lane).
+    ``eval_jac`` : state RHS + non-zeros of J_y and J_p -- the part that is
+                   identical for every sensitivity column of a trajectory.
+    ``apply_col``: dz = J_y z + J_p[:, scol] for ONE column held in registers;
+                   fully unrolled with static indices so that ``z``/``dz`` stay
+                   in VGPRs.
+    """
+    d = derived or Derived(spec)
+    n, k = spec.n_vars, spec.n_sens
+    pr = _ExprPrinter(_symbol_map(spec), rcp="SBM_RCP(%s)", lang='hip')
+    nnz_y, nnz_p = max(len(d.jy), 1), max(len(d.jp), 1)
+    L = _fmt_header(spec, "//")
+    L += ["#pragma once", "",
+          "struct SbmModel {",
+          "  static constexpr int NV = %d;      // state variables" % n,
+          "  static constexpr int NP = %d;      // model parameters (length of p)" % spec.n_params,
+          "  static constexpr int NK = %d;      // non-fixed parameters = sensitivity columns" % k,
+          "  static constexpr int NNZ_JY = %d;  // non-zeros of df/dy" % len(d.jy),
+          "  static constexpr int NNZ_JP = %d;  // non-zeros of df/dp" % len(d.jp),
+          "  static constexpr int NJY = %d;" % nnz_y,
+          "  static constexpr int NJP = %d;" % nnz_p,
+          "  static constexpr const char* NAME = \"%s\";" % spec.name, ""]
+    # eval_f
+    L += ["  template <class PA>",
+          "  __device__ __forceinline__ static void eval_f(double t, const double (&y)[NV], const PA& p,",
+          "                                                double (&f)[NV]) {", "    (void)t;"]
+    for s, e in d.repl_f:
+        L.append("    const double %s = %s;" % (s, pr.doprint(e)))
+    for i, e in enumerate(d.f_only):
+        L.append("    f[%d] = %s;" % (i, pr.doprint(e)))
+    L += ["  }", ""]
+    # eval_jac
+    L += ["  template <class PA>",
+          "  __device__ __forceinline__ static void eval_jac(double t, const double (&y)[NV], const PA& p,",
+          "                                                  double (&f)[NV], double (&jy)[NJY], double (&jp)[NJP]) {",
+          "    (void)t;"]
+    for s, e in d.repl_all:
+        L.append("    const double %s = %s;" % (s, pr.doprint(e)))
+    for i, e in enumerate(d.f_red):
+        L.append("    f[%d] = %s;" % (i, pr.doprint(e)))
+    for e_idx, e in enumerate(d.jy_red):
+        L.append("    jy[%d] = %s;" % (e_idx, pr.doprint(e)))
+    for e_idx, e in enumerate(d.jp_red):
+        L.append("    jp[%d] = %s;" % (e_idx, pr.doprint(e)))
+    if not d.jy:
+        L.append("    jy[0] = 0.0;")
+    if not d.jp:
+        L.append("    jp[0] = 0.0;")
+    L += ["  }", ""]
+    # apply_col
+    L += ["  // one sensitivity column: dz = J_y z + J_p[:, scol]   (scol < 0: no J_p term)",
+          "  __device__ __forceinline__ static void apply_col(const double (&jy)[NJY], const double (&jp)[NJP],",
+          "                                                   int scol, const double (&z)[NV], double (&dz)[NV]) {"]
+    for i in range(n):
+        sel = "0.0"
+        for e_idx, c in reversed(d.jp_rows[i]):
+            sel = "(scol == %d ? jp[%d] : %s)" % (c, e_idx, sel)
+        expr = sel
+        for e_idx, c in d.jy_rows[i]:
+            expr = "fma(jy[%d], z[%d], %s)" % (e_idx, c, expr)
+        L.append("    dz[%d] = %s;" % (i, expr))
+    L += ["  }", "};", ""]
+    return "\n".join(L)
