@@ -47,6 +47,9 @@ typedef struct sbm_integrator_opts {
   double rtol;       /* DOPRI45 relative tolerance                               */
   double atol;       /* DOPRI45 absolute tolerance                               */
   double h0;         /* RK4: step size; DOPRI45: initial step (<=0 -> automatic) */
+  double t0;         /* time of the initial condition; output times must be >= t0.
+                      * odeint takes t_sim[0] for it (model/ode_model.py:122,167);
+                      * Project always integrates from 0 (base_project.py:419)     */
 } sbm_integrator_opts;
 
 /* per-trajectory status written next to the results (the reference does not
@@ -82,8 +85,8 @@ int sbm_model_info(const sbm_model* m, int32_t* n_vars, int32_t* n_params, int32
 
 /* ---- OdeModel.simulate (model/ode_model.py:128-169), batched ------------ */
 /* P      [V][n_params]            one parameter vector per trajectory
- * t_out  [n_t]                    non-decreasing output times, t_out[0] >= 0;
- *                                 integration starts at t = 0
+ * t_out  [n_t]                    non-decreasing output times, t_out[0] >= opts->t0;
+ *                                 integration starts at t = opts->t0
  * y0     [n_vars] or NULL         initial state (NULL -> zeros, as the
  *                                 reference's default, ode_model.py:151-152)
  * Y      [V][n_t][n_vars]         out

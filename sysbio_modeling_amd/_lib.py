@@ -24,7 +24,8 @@ class SbmError(RuntimeError):
 
 class IntegratorOpts(ctypes.Structure):
     _fields_ = [('method', ctypes.c_int32), ('max_steps', ctypes.c_int32),
-                ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double)]
+                ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double),
+                ('t0', ctypes.c_double)]
 
 
 class ProjectDesc(ctypes.Structure):
@@ -114,7 +115,7 @@ def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None):
+def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None, t0=0.0):
     """IntegratorOpts from keywords.  For 'rk4' give h0 or (n_steps, t_end)."""
     if isinstance(method, str):
         key = method.lower()
@@ -129,8 +130,8 @@ def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_st
     if m == SBM_RK4_FIXED and not h0 > 0.0:
         if n_steps is None or t_end is None:
             raise ValueError("rk4 needs h0, or n_steps together with t_end")
-        h0 = float(t_end) / int(n_steps)
-    return IntegratorOpts(m, int(max_steps), float(rtol), float(atol), float(h0))
+        h0 = (float(t_end) - float(t0)) / int(n_steps)
+    return IntegratorOpts(m, int(max_steps), float(rtol), float(atol), float(h0), float(t0))
 
 
 # ---------------------------------------------------------------------------

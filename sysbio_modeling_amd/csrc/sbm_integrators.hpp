@@ -45,6 +45,16 @@ __device__ __forceinline__ double sbm_rcp(double x) {
 }
 #define SBM_RCP(x) sbm_rcp(x)
 
+// J_p[row, scol] picked per lane.  Arguments BY VALUE: the candidates are computed
+// unconditionally and this lowers to v_cndmask -- written as a ?: chain over array
+// elements hipcc sinks the J_p arithmetic into exec-masked branches (one per non-zero).
+__device__ __forceinline__ double sbm_pick(int scol, int c, double v, double otherwise) {
+  return scol == c ? v : otherwise;
+}
+#define SBM_PICK(scol, c, v, otherwise) sbm_pick(scol, c, v, otherwise)
+__device__ __forceinline__ double sbm_sel(bool c, double a, double b) { return c ? a : b; }
+#define SBM_SEL(c, a, b) sbm_sel(c, a, b)
+
 __device__ __forceinline__ double sbm_bcast0(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -106,15 +116,21 @@ struct SensSystem {
   int lane;
 
   __device__ __forceinline__ void rhs(double t, const double (&z)[CPL][NV], double (&dz)[CPL][NV]) const {
-    double y[NV], f[NV], jy[M::NJY], jp[M::NJP];
+    double y[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) y[i] = sbm_bcast0(z[0][i]);
-    M::eval_jac(t, y, p, f, jy, jp);
+    if constexpr (CPL == 1) {
+      // fused, row by row: J entries are consumed as they are produced
+      M::eval_col(t, y, p, lane - 1, z[0], dz[0]);
+    } else {
+      double f[NV], jy[M::NJY], jp[M::NJP];
+      M::eval_jac(t, y, p, f, jy, jp);
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) M::apply_col(jy, jp, lane + 64 * c - 1, z[c], dz[c]);
-    const bool state_lane = (lane == 0);
+      for (int c = 0; c < CPL; ++c) M::apply_col(jy, jp, lane + 64 * c - 1, z[c], dz[c]);
+      const bool state_lane = (lane == 0);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) dz[0][i] = state_lane ? f[i] : dz[0][i];
+      for (int i = 0; i < NV; ++i) dz[0][i] = sbm_sel(state_lane, f[i], dz[0][i]);
+    }
   }
   // error norm: max over columns of the column's RMS (every column, the state
   // included, individually meets the tolerance -- the CVODES-style sens. test)
@@ -170,10 +186,10 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
   const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000;
 
   double k1[CPL][NV], k2[CPL][NV], k3[CPL][NV], k4[CPL][NV], k5[CPL][NV], k6[CPL][NV], zt[CPL][NV];
-  double t = 0.0;
+  double t = o.t0;
   SbmTrajOut out{SBM_OK, 0, 0};
   if (n_t <= 0) return out;
-  const double t_last = t_out[n_t - 1];
+  const double t_span = t_out[n_t - 1] - o.t0;
 
   sys.rhs(t, z, k1);
 
@@ -190,7 +206,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
     dnf = sys.sum(dnf);
     dny = sys.sum(dny);
     h = (dnf <= 1e-10 || dny <= 1e-10) ? 1e-6 : sqrt(dny / dnf) * 0.01;
-    h = fmin(h, t_last > 0.0 ? t_last : 1.0);
+    h = fmin(h, t_span > 0.0 ? t_span : 1.0);
     SBM_ALL(c, i) zt[c][i] = fma(h, k1[c][i], z[c][i]);
     sys.rhs(t + h, zt, k2);
     double der2 = 0.0;
@@ -202,7 +218,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
     der2 = sqrt(sys.sum(der2)) / h;
     const double der12 = fmax(fabs(der2), sqrt(dnf));
     const double h1 = (der12 <= 1e-15) ? fmax(1e-6, fabs(h) * 1e-3) : pow(0.01 / der12, 0.2);
-    h = fmin(fmin(100.0 * h, h1), t_last > 0.0 ? t_last : 1.0);
+    h = fmin(fmin(100.0 * h, h1), t_span > 0.0 ? t_span : 1.0);
     if (!(h > 0.0)) h = 1e-6;
   }
 
@@ -311,7 +327,7 @@ __device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::C
   SbmTrajOut out{SBM_OK, 0, 0};
   const double h0 = o.h0;
   const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000000;
-  double t = 0.0;
+  double t = o.t0;
   bool failed = !(h0 > 0.0);
   if (failed) out.status = SBM_STEP_UNDERFLOW;
   for (int io = 0; io < n_t; ++io) {

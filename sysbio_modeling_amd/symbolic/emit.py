@@ -26,6 +26,24 @@ from . import sympy_tools
 _RCP = sympy.Function('SBM_RCP')
 
 
+def _cheapest(expr):
+    """Derivatives of rational rate laws come out of ``diff`` as sums such as
+    k/(1+x) - k*x/(1+x)**2; the factored form k/(1+x)**2 is a third of the work.
+    Pick the cheapest of raw / factored / simplified (divisions weighted heavily)."""
+    def cost(e):
+        return sympy.count_ops(e, visual=False) + 8 * len([a for a in sympy.preorder_traversal(e)
+                                                           if a.is_Pow and a.exp.is_number and a.exp.is_negative])
+    best = expr
+    for f in (sympy.factor, sympy.simplify):
+        try:
+            cand = f(expr)
+        except Exception:
+            continue
+        if cost(cand) < cost(best):
+            best = cand
+    return best
+
+
 def _canon_rcp(expr):
     """b**(-n) -> SBM_RCP(b)**n (integer n) so that CSE shares ONE reciprocal per
     distinct denominator; reciprocals dominate the cost of rate-law right-hand sides."""
@@ -104,7 +122,8 @@ class Derived:
         self.jy = jy  # (row, col, expr)
         self.jp = jp  # (row, sens col, expr)
         f_exprs = [_canon_rcp(sympy.sympify(spec.equations[v])) for v in spec.variables]
-        all_exprs = f_exprs + [_canon_rcp(e) for _, _, e in jy] + [_canon_rcp(e) for _, _, e in jp]
+        all_exprs = f_exprs + [_canon_rcp(_cheapest(e)) for _, _, e in jy] + \
+            [_canon_rcp(_cheapest(e)) for _, _, e in jp]
         # joint CSE: subexpressions of f are shared with its derivatives
         self.repl_all, red_all = cse(all_exprs, symbols=sympy.numbered_symbols('x_'),
                                      optimizations='basic')
@@ -353,10 +372,44 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     for i in range(n):
         sel = "0.0"
         for e_idx, c in reversed(d.jp_rows[i]):
-            sel = "(scol == %d ? jp[%d] : %s)" % (c, e_idx, sel)
+            sel = "SBM_PICK(scol, %d, jp[%d], %s)" % (c, e_idx, sel)
         expr = sel
         for e_idx, c in d.jy_rows[i]:
             expr = "fma(jy[%d], z[%d], %s)" % (e_idx, c, expr)
         L.append("    dz[%d] = %s;" % (i, expr))
+    L += ["  }", ""]
+    # eval_col: the two above fused row by row.  Same arithmetic; every J_y / J_p entry is
+    # consumed right after it is computed, which keeps the live set (and the VGPR count of
+    # the 7-stage Dormand-Prince kernel) down.  Each CSE temporary is emitted before its first use.
+    L += ["  // fused eval_jac + apply_col for ONE column per lane: scol < 0 -> dz = f (state lane),",
+          "  // scol in [0, NK) -> dz = J_y z + J_p[:, scol]",
+          "  template <class PA>",
+          "  __device__ __forceinline__ static void eval_col(double t, const double (&y)[NV], const PA& p, int scol,",
+          "                                                  const double (&z)[NV], double (&dz)[NV]) {",
+          "    (void)t;", "    const bool state_lane = scol < 0;"]
+    temp_expr = OrderedDict((s, e) for s, e in d.repl_all)
+    emitted = set()
+
+    def need(expr, out):
+        for s in sorted(expr.free_symbols, key=lambda x: x.name):
+            if s in temp_expr and s not in emitted and s not in out:
+                need(temp_expr[s], out)
+                out.append(s)
+
+    for i in range(n):
+        exprs = [d.f_red[i]] + [d.jy_red[e] for e, _ in d.jy_rows[i]] + [d.jp_red[e] for e, _ in d.jp_rows[i]]
+        todo = []
+        for e in exprs:
+            need(e, todo)
+        for s in todo:
+            L.append("    const double %s = %s;" % (s, pr.doprint(temp_expr[s])))
+            emitted.add(s)
+        sel = "0.0"
+        for e_idx, c in reversed(d.jp_rows[i]):
+            sel = "SBM_PICK(scol, %d, %s, %s)" % (c, pr.doprint(d.jp_red[e_idx]), sel)
+        expr = sel
+        for e_idx, c in d.jy_rows[i]:
+            expr = "fma(%s, z[%d], %s)" % (pr.doprint(d.jy_red[e_idx]), c, expr)
+        L.append("    dz[%d] = SBM_SEL(state_lane, %s, %s);" % (i, pr.doprint(d.f_red[i]), expr))
     L += ["  }", "};", ""]
     return "\n".join(L)

@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+# parity tolerance of the integration path, stated once (DESIGN.md section "Parity"):
+# the reference answer is SciPy odeint at rtol = atol = 1e-10 (model/ode_model.py:123,168),
+# itself only ~1e-9 accurate in ABSOLUTE terms (atol term); two correct solvers therefore
+# agree to 1e-8 relative plus LSODA's own absolute noise.
+PARITY_RTOL = 1e-8
+PARITY_ATOL = 5e-9
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def parity_err(a, b):
+    """max |a-b| / (PARITY_ATOL + PARITY_RTOL |b|): <= 1 means within the stated tolerance."""
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b) / (PARITY_ATOL + PARITY_RTOL * np.abs(b)))) if a.size else 0.0
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name))
+    return load
+
+
+@pytest.fixture(scope='session')
+def zoo():
+    from sysbio_modeling_amd.symbolic import zoo_model
+    return zoo_model
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope='session')
+def gpu_models(zoo):
+    """OdeModel per zoo model, loaded on cuda:0 (gpu tests only)."""
+    from sysbio_modeling_amd.model import OdeModel
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            gm = zoo(name)
+            cache[name] = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=name)
+        return cache[name]
+    return get

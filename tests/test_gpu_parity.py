@@ -1,0 +1,462 @@
+"""Parity tests proper (need an MI355X): the HIP path, called through the C ABI, against
+  * golden vectors produced by the real reference OdeModel (tests/golden/),
+  * the oracle (SciPy odeint restatement) run live on the same seeded inputs,
+  * the reference's own known answers (tests/test_OdeModel.py, tests/test_Project.py),
+and, at BASELINE.json's full ensemble size, through size-independent properties.
+
+Tolerance: |gpu - ref| <= 1e-8 |ref| + 5e-9  (conftest.PARITY_*; the absolute term is the
+reference integrator's own noise: LSODA at atol = 1e-10 is ~1e-9 accurate in absolute terms,
+measured against DOP853 at rtol 1e-13 in test_gpu_is_closer_to_tight_solution_than_lsoda)."""
+import ctypes
+import warnings
+
+import numpy as np
+import pytest
+
+from tests import reference_cases as rc
+from tests.conftest import parity_err, PARITY_RTOL, PARITY_ATOL
+
+pytestmark = pytest.mark.gpu
+
+METHODS = [('dopri45', {}), ('rk4', {'n_steps': 16384})]
+
+
+def _from_zero(t_pts):
+    """Output grid starting at the initial time 0 (odeint semantics: t_sim[0] is t0)."""
+    return np.concatenate([[0.0], np.asarray(t_pts, dtype=float)])
+
+
+# ---------------------------------------------------------------------------
+# OdeModel.simulate / calc_jacobian
+# ---------------------------------------------------------------------------
+def test_reference_test_odemodel_simulate(gpu_models):
+    """tests/test_OdeModel.py:20-29."""
+    m = gpu_models('simple')
+    assert m.n_vars == 1
+    y = m.simulate(rc.SIMPLE_P, rc.SIMPLE_T10)
+    assert y.shape == (10, 1)
+    assert np.allclose(y[:, 0], rc.SIMPLE_Y10_GOLDEN, rtol=0.05)
+    exact, _, _ = rc.simple_closed_form(rc.SIMPLE_P[0], rc.SIMPLE_P[1], rc.SIMPLE_T10)
+    assert np.allclose(y[:, 0], exact, rtol=1e-9, atol=1e-12)
+
+
+def test_reference_test_odemodel_calc_jacobian(gpu_models):
+    """tests/test_OdeModel.py:31-52 (with the correct closed form for d/dk_deg)."""
+    m = gpu_models('simple')
+    s = m.calc_jacobian(rc.SIMPLE_P, rc.SIMPLE_T10, np.zeros(3))
+    assert s.shape == (10, 2)
+    _, d_kdeg, d_ksynt = rc.simple_closed_form(rc.SIMPLE_P[0], rc.SIMPLE_P[1], rc.SIMPLE_T10)
+    assert np.allclose(s[:, 1], d_ksynt, rtol=0.05) and np.allclose(s[:, 0], d_kdeg, rtol=0.05)
+    assert np.allclose(s[:, 1], d_ksynt, rtol=1e-9, atol=1e-12)
+    assert np.allclose(s[:, 0], d_kdeg, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize('method,kw', METHODS)
+@pytest.mark.parametrize('name,file', [('simple', 'simple_ref.npz'), ('michaelis_menten', 'mm_ref.npz')])
+def test_golden_full_grid(gpu_models, golden, name, file, method, kw):
+    """1000-point trajectories of the REAL reference OdeModel, both parameter sets."""
+    m = gpu_models(name)
+    g = golden(file)
+    Y = m.simulate_batch(g['P'], g['t'], method=method, **kw)
+    S, Y2 = m.calc_jacobian_batch(g['P'], g['t'], return_states=True, method=method, **kw)
+    assert Y.shape == g['Y'].shape and S.shape == g['S'].shape
+    assert parity_err(Y, g['Y']) <= 1.0
+    assert parity_err(Y2, g['Y']) <= 1.0
+    assert parity_err(S, g['S']) <= 1.0
+
+
+@pytest.mark.parametrize('method,kw', METHODS)
+def test_golden_cascade20(gpu_models, golden, method, kw):
+    """20-state / 40-parameter network, 820 coupled ODEs: rows the reference OdeModel produced on
+    its 1000-point grid at the 16 measurement times."""
+    m = gpu_models('cascade20')
+    g = golden('cascade20_ref.npz')
+    t_out = _from_zero(g['t'][g['idx']])
+    Y = m.simulate_batch(g['P'], t_out, method=method, **kw)[:, 1:]
+    S, Y2 = m.calc_jacobian_batch(g['P'], t_out, return_states=True, method=method, **kw)
+    assert parity_err(Y, g['Y']) <= 1.0
+    assert parity_err(Y2[:, 1:], g['Y']) <= 1.0
+    assert parity_err(S[:, 1:], g['S']) <= 1.0
+    assert np.all(Y2[:, 0] == 0) and np.all(S[:, 0] == 0)     # initial condition row is returned untouched
+
+
+def test_live_oracle_random_vectors(gpu_models, zoo):
+    from oracle import odeint_oracle as oo
+    from sysbio_modeling_amd import models_zoo
+    gm = zoo('cascade20')
+    m = gpu_models('cascade20')
+    _, P = models_zoo.cascade_ensemble(4096)
+    pick = [5, 777, 4095]
+    grid = np.linspace(0, 100, 1000)
+    idx = np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)
+    S, Y = m.calc_jacobian_batch(P[pick], _from_zero(grid[idx]), return_states=True)
+    for k, v in enumerate(pick):
+        (Sr, Yr) = oo.calc_jacobian(gm, P[v], grid, use_c=True, return_states=True)
+        assert parity_err(Y[k, 1:], Yr[idx]) <= 1.0
+        assert parity_err(S[k, 1:], Sr[idx]) <= 1.0
+
+
+def test_gpu_is_closer_to_tight_solution_than_lsoda(gpu_models, zoo):
+    """'GPU more accurate than the reference' must be distinguishable from 'GPU wrong'."""
+    from oracle import odeint_oracle as oo
+    gm = zoo('michaelis_menten')
+    m = gpu_models('michaelis_menten')
+    t = np.linspace(0, 100, 50)
+    tight = oo.tight_solution(gm, rc.MM_PARAMS, t)
+    S, Y = m.calc_jacobian_batch(rc.MM_PARAMS[None, :], t, return_states=True, rtol=1e-11, atol=1e-14)
+    Sl, Yl = oo.calc_jacobian(gm, rc.MM_PARAMS, t, return_states=True)
+    e_gpu = max(np.max(np.abs(Y[0] - tight[:, :2])), np.max(np.abs(S[0] - tight[:, 2:])))
+    e_lsoda = max(np.max(np.abs(Yl - tight[:, :2])), np.max(np.abs(Sl - tight[:, 2:])))
+    assert e_gpu < 1e-9 and e_gpu <= e_lsoda
+
+
+def test_initial_conditions_and_start_time(gpu_models, zoo):
+    from oracle import odeint_oracle as oo
+    gm = zoo('michaelis_menten')
+    m = gpu_models('michaelis_menten')
+    t = np.linspace(3.0, 40.0, 12)            # odeint: the initial condition holds at t_sim[0] = 3
+    y0 = np.array([0.01, 0.002])
+    Y = m.simulate(rc.MM_PARAMS, t, y0)
+    assert np.array_equal(Y[0], y0)
+    assert parity_err(Y, oo.simulate(gm, rc.MM_PARAMS, t, y0)) <= 1.0
+    rng = np.random.default_rng(2)
+    yS0 = np.concatenate([y0, 1e-3 * rng.standard_normal(10)])
+    S = m.calc_jacobian(rc.MM_PARAMS, t, yS0)
+    assert np.array_equal(S[0], yS0[2:])
+    assert parity_err(S, oo.calc_jacobian(gm, rc.MM_PARAMS, t, yS0)) <= 1.0
+    with pytest.raises(ValueError):
+        m.simulate(rc.MM_PARAMS, t, np.zeros(3))
+    with pytest.raises(ValueError):
+        m.simulate(rc.MM_PARAMS, t[::-1])
+
+
+def test_edge_grids(gpu_models):
+    m = gpu_models('simple')
+    # one output = the initial time only; repeated output times; empty ensemble
+    y = m.simulate(rc.SIMPLE_P, np.array([0.0]))
+    assert y.shape == (1, 1) and y[0, 0] == 0.0
+    t = np.array([0.0, 10.0, 10.0, 10.0, 50.0])
+    y = m.simulate(rc.SIMPLE_P, t)[:, 0]
+    exact, _, _ = rc.simple_closed_form(rc.SIMPLE_P[0], rc.SIMPLE_P[1], t)
+    assert y[1] == y[2] == y[3] and np.allclose(y, exact, rtol=1e-9, atol=1e-13)
+    assert m.simulate_batch(np.zeros((0, 2)), t).shape == (0, 5, 1)
+    assert m.calc_jacobian_batch(np.zeros((0, 2)), t).shape == (0, 5, 2)
+    with pytest.raises(ValueError):
+        m.simulate_batch(np.zeros((3, 5)), t)
+
+
+def test_failures_are_reported_not_hidden(gpu_models):
+    """The reference never checks LSODA's status; here every trajectory carries one and failed
+    rows are NaN (the Project layer turns them into the reference's inf rows)."""
+    m = gpu_models('simple')
+    P = np.array([[0.001, 0.01], [np.nan, 0.01], [0.001, 0.01]])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        Y = m.simulate_batch(P, rc.SIMPLE_T10)
+        assert any('failed' in str(x.message) for x in w)
+    assert m.last_info['status'].tolist() == [0, 2, 0]
+    assert np.all(np.isnan(Y[1, 1:])) and np.all(np.isfinite(Y[0])) and np.array_equal(Y[0], Y[2])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        S = m.calc_jacobian_batch(P[:1], rc.SIMPLE_T10, max_steps=3)
+    assert m.last_info['status'].tolist() == [1] and np.all(np.isnan(S[0, -1]))
+
+
+def test_c_abi_device_pointers_and_determinism(gpu_models):
+    """Straight through sbm_sens_batch with caller-owned device buffers; a vector's result does
+    not depend on what else is in the batch (bitwise)."""
+    import torch
+    from sysbio_modeling_amd import _lib, models_zoo
+    m = gpu_models('cascade20')
+    dm = m.device_model
+    _, P = models_zoo.cascade_ensemble(256)
+    t = _from_zero(models_zoo.CASCADE_MEASURE_TIMES)
+    Pd, td = torch.from_numpy(P).cuda(), torch.from_numpy(t).cuda()
+    V, nt = P.shape[0], len(t)
+    Y = torch.full((V, nt, 20), float('nan'), dtype=torch.float64, device='cuda')
+    S = torch.full((V, nt, 20, 40), float('nan'), dtype=torch.float64, device='cuda')
+    st = torch.full((V,), -1, dtype=torch.int32, device='cuda')
+    ns = torch.zeros_like(st)
+    opts = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+    dm.sens_dev(Pd, td, None, opts, Y, S, st, ns, None)
+    torch.cuda.synchronize()
+    assert int((st != 0).sum()) == 0 and int(ns.min()) > 50 and bool(torch.isfinite(S).all())
+    S1, Y1 = m.calc_jacobian_batch(P[17:18], t, return_states=True)
+    assert np.array_equal(S1[0].reshape(nt, 20, 40), S[17].cpu().numpy())
+    assert np.array_equal(Y1[0], Y[17].cpu().numpy())
+    # NULL arguments are refused, not dereferenced
+    rc_ = dm.lib.sbm_sens_batch(dm.handle, None, V, _lib.dev_ptr(td), nt, None, ctypes.byref(opts), None, None,
+                                None, None, None)
+    assert rc_ != 0 and b'NULL' in dm.lib.sbm_last_error()
+
+
+# ---------------------------------------------------------------------------
+# full ensemble size: size-independent properties (BASELINE.json configs[1], configs[2])
+# ---------------------------------------------------------------------------
+def test_full_ensemble_properties(gpu_models):
+    import torch
+    from sysbio_modeling_amd import _lib, models_zoo
+    m = gpu_models('cascade20')
+    dm = m.device_model
+    theta, P = models_zoo.cascade_ensemble(4096)
+    t = _from_zero(models_zoo.CASCADE_MEASURE_TIMES)
+    V, nt = 4096, len(t)
+    Pd, td = torch.from_numpy(P).cuda(), torch.from_numpy(t).cuda()
+
+    def run(kind, opts, Pdev=Pd):
+        Y = torch.empty((V, nt, 20), dtype=torch.float64, device='cuda')
+        S = torch.empty((V, nt, 20, 40), dtype=torch.float64, device='cuda') if kind == 'sens' else None
+        st = torch.empty((V,), dtype=torch.int32, device='cuda')
+        if kind == 'sens':
+            dm.sens_dev(Pdev, td, None, opts, Y, S, st, None, None)
+        else:
+            dm.simulate_dev(Pdev, td, None, opts, Y, st, None, None)
+        torch.cuda.synchronize()
+        assert int((st != 0).sum()) == 0
+        return Y, S
+
+    dop = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+    rk4 = _lib.make_opts('rk4', n_steps=16384, t_end=100.0)
+    Ya, Sa = run('sens', dop)
+    Yb, Sb = run('sens', rk4)
+    Yc, _ = run('state', dop)
+
+    def perr(a, b):
+        return float(torch.max(torch.abs(a - b) / (PARITY_ATOL + PARITY_RTOL * torch.abs(b))))
+    # 1. two unrelated integrators agree on all 4096 x 16 x 820 values
+    assert perr(Ya, Yb) <= 1.0 and perr(Sa, Sb) <= 1.0
+    # 2. the state computed alone (one trajectory per lane) equals the state column of the augmented run
+    assert perr(Yc, Ya) <= 1.0
+    # 3. sensitivities are derivatives: central differences of the state w.r.t. three parameters
+    for j in (0, 23, 39):
+        d = 1e-5 * P[:, j]
+        Pp, Pm = P.copy(), P.copy()
+        Pp[:, j] += d
+        Pm[:, j] -= d
+        Yp, _ = run('state', dop, torch.from_numpy(Pp).cuda())
+        Ym, _ = run('state', dop, torch.from_numpy(Pm).cuda())
+        fd = (Yp - Ym) / torch.from_numpy(2 * d).cuda()[:, None, None]
+        s = Sa[:, :, :, j]
+        scale = torch.amax(torch.abs(s), dim=(1, 2), keepdim=True)
+        assert float(torch.max(torch.abs(fd - s) / (scale + 1e-12))) < 1e-5
+
+
+# ---------------------------------------------------------------------------
+# Project
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def simple_case(gpu_models, zoo):
+    from oracle.project_oracle import ProjectOracle
+    from sysbio_modeling_amd.project import Project
+    exps, settings, mapping, sf = rc.simple_project_case()
+    proj = Project(gpu_models('simple'), exps, settings, mapping, sf_groups=sf)
+    exps2, _, _, _ = rc.simple_project_case()
+    po = ProjectOracle(zoo('simple'), exps2, settings, mapping, sf_groups=sf)
+    theta = rc.simple_project_theta(proj.get_param_index)
+    return proj, po, theta
+
+
+def test_reference_test_sim_experiments(simple_case):
+    """tests/test_Project.py:96-117."""
+    proj, po, theta = simple_case
+    res = proj.residuals(theta)
+    assert res.shape == (35,)
+    sims = proj.get_simulations()
+    assert len(set(sims.index.get_level_values(0))) == 2
+    for exp in proj.experiments:
+        data, _, _ = exp.get_variable_measurements('Variable_1').get_nonzero_measurements()
+        sim = sims.loc[(exp.name, 'Variable_1'), 'mean'].values
+        assert np.allclose(data / 3.75, sim, rtol=0.05)
+    assert np.allclose(proj.scale_factors['Variable_1'].sf, 3.75, rtol=0.05)
+    ref, ref_sims, B = po.residuals(theta, return_parts=True)
+    assert parity_err(res, ref) <= 1.0 and parity_err(sims['mean'].values, ref_sims) <= 1.0
+    assert abs(proj.scale_factors['Variable_1'].sf - B[0]) <= 1e-8 * B[0]
+    scaled = proj.get_simulations(scaled=True)['mean'].values
+    assert parity_err(scaled, ref_sims * B[0]) <= 1.0
+    # sampled grid times, not measurement times (project/utils.py:21)
+    assert sims['timepoints'].values[0] == pytest.approx(np.linspace(0, HIGH_T_END, 1000)[
+        np.searchsorted(np.linspace(0, HIGH_T_END, 1000), rc.HIGH_DEG_T[0])])
+
+
+HIGH_T_END = rc.HIGH_DEG_T[-1]
+
+
+def test_reference_test_variable_jacobian(simple_case):
+    """tests/test_Project.py:119-143."""
+    proj, po, theta = simple_case
+    proj.calc_project_jacobian(theta)
+    model_jac = proj.get_model_jacobian_df()
+    p = np.exp(theta)
+    for exp in proj.experiments:
+        ks, kd = exp.param_global_vector_idx['k_synt'], exp.param_global_vector_idx['k_deg']
+        t = exp.get_variable_measurements('Variable_1').timepoints
+        t = t[t != 0]
+        anal = rc.simple_model_analytical_jac(p[kd], p[ks], t)
+        blk = model_jac.loc[(exp.name, 'Variable_1'), :].values
+        assert np.allclose(anal[1], blk[:, ks], rtol=0.05) and np.allclose(anal[0], blk[:, kd], rtol=0.05)
+    assert parity_err(model_jac.values, po.model_jacobian(theta)) <= 1.0
+
+
+def test_reference_test_calc_project_jacobian(simple_case):
+    """tests/test_Project.py:145-176: FD identities, then parity with the oracle."""
+    proj, po, theta = simple_case
+    J = proj.calc_project_jacobian(theta)
+    assert J.shape == (35, 3)
+
+    def scaled_sims(x):
+        proj.residuals(x)
+        return proj.get_simulations(scaled=True)['mean'].values
+    assert np.allclose(rc.central_fd_jacobian(scaled_sims, theta), J, atol=1e-6)
+    th2 = theta.copy()
+    th2[proj.get_param_index('Group_1', ('High',))] = np.log(0.02)
+    th2[proj.get_param_index('Group_1', ('Low',))] = np.log(0.003)
+    th2[proj.get_param_index('k_synt', 'Global')] = np.log(0.05)
+    g = proj.calc_rss_gradient(th2)
+    gnum = rc.central_fd_jacobian(lambda x: np.array([proj.calc_sum_square_residuals(x)]), th2)[0]
+    assert np.allclose(g, gnum, atol=1e-6)
+    assert parity_err(J, po.calc_project_jacobian(theta)) <= 1.0
+    assert np.allclose(g, po.calc_rss_gradient(th2), rtol=1e-7, atol=1e-9)
+    grad = np.zeros(3)
+    val = proj.nlopt_fcn(th2, grad)                                   # :829-852
+    assert np.allclose(grad, g) and val == pytest.approx(po.calc_sum_square_residuals(th2), rel=1e-8)
+    sfg = proj.scale_factors['Variable_1'].gradient
+    assert sfg.shape == (3,)
+
+
+def test_reference_test_optimization(simple_case):
+    """tests/test_Project.py:202-213: leastsq driven by residuals + Dfun runs and fits."""
+    from scipy.optimize import leastsq
+    proj, _, theta = simple_case
+    base_guess = np.log(np.ones(3) * 0.01)
+    out, ier = leastsq(proj.residuals, base_guess, Dfun=proj.calc_project_jacobian)
+    assert ier in (1, 2, 3, 4)
+    assert proj.calc_sum_square_residuals(out) <= proj.calc_sum_square_residuals(base_guess)
+
+
+def test_reference_test_sum_variables(gpu_models, zoo):
+    """tests/test_Project.py:263-349: Michaelis-Menten, 'sum' of both species, no scale factors."""
+    from oracle import odeint_oracle as oo
+    from oracle.project_oracle import ProjectOracle
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    gm = zoo('michaelis_menten')
+    sim = oo.simulate(gm, rc.MM_PARAMS, rc.MM_T)
+    mk = lambda: Experiment('Standard', TimecourseMeasurement('Total', sim.sum(axis=1), rc.MM_T))
+    with pytest.warns(UserWarning):
+        proj = Project(gpu_models('michaelis_menten'), [mk()], {}, {'Total': ('sum', [0, 1])})
+    po = ProjectOracle(gm, [mk()], {}, {'Total': ('sum', [0, 1])})
+    for param in proj.project_param_idx:
+        assert list(proj.project_param_idx[param].keys()) == ['Global']
+    pdict = {n: {'Global': v} for n, v in zip(gm.param_order, rc.MM_PARAMS)}
+    theta = np.log(proj.project_param_dict_to_vect(pdict))
+    res = proj.residuals(theta)
+    assert np.allclose(res, 0, atol=1e-3)
+    g = proj.calc_rss_gradient(theta)
+    gnum = rc.central_fd_jacobian(lambda x: np.array([proj.calc_sum_square_residuals(x)]), theta)[0]
+    assert np.allclose(g, gnum, atol=1e-5)
+    J = proj.calc_project_jacobian(theta)
+
+    def all_sims(x):
+        proj.residuals(x)
+        return proj.get_simulations()['mean'].values
+    assert np.allclose(J, rc.central_fd_jacobian(all_sims, theta), atol=1e-5)
+    assert parity_err(J, po.calc_project_jacobian(theta)) <= 1.0
+    assert parity_err(all_sims(theta), po.residuals(theta, return_parts=True)[1]) <= 1.0
+
+
+def _cascade_project(gpu_models, zoo, n_exp=3, compat=True, fixed=False, priors=False):
+    """A small version of BASELINE.json configs[3]: shared d0..d3 by condition, several measures per
+    experiment, one scale-factor group per measured species (plus a two-measure group)."""
+    from oracle.project_oracle import ProjectOracle
+    from oracle import odeint_oracle as oo
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    gm = zoo('cascade20')
+    rng = np.random.default_rng(7)
+    p_nom = models_zoo.cascade_nominal_params()
+    names = gm.param_order
+    settings = {'Shared': {'deg': {('d%d' % i): ('cond',) for i in range(4)}},
+                'Global': [n for n in names if n not in ('d0', 'd1', 'd2', 'd3')]}
+    mapping = {'s4': ('direct', 4), 's9': ('direct', 9), 's14': ('direct', 14), 's19': ('direct', 19),
+               'tot': ('sum', [0, 1, 2])}
+    sf = ['s4', frozenset(['s9', 's14']), 's19']
+
+    def build():
+        exps = []
+        for c in range(n_exp):
+            p = p_nom.copy()
+            p[20:24] *= (1.0 + 0.25 * c)
+            tmax = 100.0 - 10.0 * c                                   # ragged grids: t_end differs per experiment
+            tm = np.linspace(tmax / 8, tmax, 8)
+            grid = np.linspace(0, tmax, 1000)
+            y = oo.simulate(gm, p, grid, use_c=True)[np.searchsorted(grid, tm)]
+            ms = []
+            for nm, (kind, arg) in mapping.items():
+                val = y[:, arg] if kind == 'direct' else y[:, arg].sum(axis=1)
+                val = val * (2.0 if nm != 'tot' else 1.0) * (1 + 0.05 * rng.standard_normal(8))
+                ms.append(TimecourseMeasurement(nm, val, tm.copy(), 0.05 * np.abs(val) + 0.01))
+            fx = {'k3': 1.1} if (fixed and c == 1) else None
+            exps.append(Experiment('exp_%d' % c, ms, fixed_parameters=fx, experiment_settings={'cond': c}))
+        return exps
+    rng_state = rng.bit_generator.state
+    exps_a = build()
+    rng.bit_generator.state = rng_state
+    exps_b = build()
+    proj = Project(gpu_models('cascade20'), exps_a, settings, mapping, sf_groups=sf, reference_compat=compat)
+    po = ProjectOracle(gm, exps_b, settings, mapping, sf_groups=sf, reference_compat=compat)
+    if priors:
+        for obj in (proj, po):
+            obj.set_parameter_log_prior('k5', 'Global', np.log(1.2), 0.5)
+            obj.set_parameter_log_prior('deg', (1,), np.log(0.1), 0.3)
+            obj.set_scale_factor_log_prior('s19', np.log(2.0), 0.2)
+    return proj, po
+
+
+@pytest.mark.parametrize('compat,fixed,priors', [(True, False, False), (False, True, True), (True, True, True)])
+def test_project_cascade_vs_oracle(gpu_models, zoo, compat, fixed, priors):
+    proj, po = _cascade_project(gpu_models, zoo, compat=compat, fixed=fixed, priors=priors)
+    assert proj.n_project_params == po.n_project_params == 36 + 4 * 3
+    assert proj.project_param_idx == po.project_param_idx
+    rng = np.random.default_rng(99)
+    thetas = 0.1 * rng.standard_normal((3, proj.n_project_params))
+    from sysbio_modeling_amd import models_zoo
+    p_nom = models_zoo.cascade_nominal_params()
+    for name, slots in proj.project_param_idx.items():
+        for key, gi in slots.items():
+            base = p_nom[proj._model.param_order.index(name)] if name != 'deg' else 0.1
+            thetas[:, gi] += np.log(base)
+    out = proj.evaluate_batch(thetas, jacobian=True,
+                              want=('jacobian', 'model_jacobian', 'gradient', 'sf_gradient'))
+    assert out['status'].tolist() == [0, 0, 0]
+    for v in range(3):
+        ref, sims, B = po.residuals(thetas[v], return_parts=True)
+        Jref = po.calc_project_jacobian(thetas[v])
+        assert parity_err(out['sims'][v], sims) <= 1.0
+        assert np.allclose(out['sf'][v], B, rtol=1e-8)
+        # residuals divide by sigma ~ 0.06: the absolute noise floor scales with 1/sigma
+        assert np.allclose(out['residuals'][v], ref, rtol=1e-7, atol=2e-7)
+        assert out['norms'][v] == pytest.approx(np.sum(ref ** 2), rel=1e-6)
+        assert np.allclose(out['jacobian'][v], Jref, rtol=1e-6, atol=1e-6 * np.max(np.abs(Jref)))
+        assert parity_err(out['model_jacobian'][v], po.model_jacobian(thetas[v])) <= 20.0
+        assert np.allclose(out['gradient'][v], (Jref.T * ref).sum(axis=1), rtol=1e-5,
+                           atol=1e-6 * np.max(np.abs(Jref)))
+    # V = 1 through the reference-named methods gives the same numbers as the batch
+    assert np.array_equal(proj.residuals(thetas[1]), out['residuals'][1])
+    assert np.array_equal(proj.calc_project_jacobian(thetas[1]), out['jacobian'][1])
+
+
+def test_project_failed_vector_gives_inf_rows(gpu_models, zoo):
+    """NaN simulations -> inf residuals and inf Jacobian (squared_loss_function.py:28-32,46-50)."""
+    proj, _ = _cascade_project(gpu_models, zoo, n_exp=2)
+    th = np.zeros((2, proj.n_project_params))
+    th[1, 3] = np.nan
+    out = proj.evaluate_batch(th, jacobian=True, want=('jacobian',))
+    assert out['status'][0] == 0 and out['status'][1] != 0
+    assert np.all(np.isinf(out['residuals'][1])) and np.all(np.isinf(out['jacobian'][1]))
+    assert np.all(np.isfinite(out['residuals'][0])) and np.all(np.isfinite(out['jacobian'][0]))
+    with pytest.warns(UserWarning, match="integration failed"):
+        r = proj.residuals(th[1])
+    assert np.all(np.isinf(r))

@@ -1,0 +1,165 @@
+"""Emitter tests (CPU): the three generated targets agree, and the HIP text -- compiled
+on the host with device qualifiers stubbed -- computes the same augmented RHS as the
+Python callables the oracle integrates."""
+import ctypes
+import io
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import sympy
+
+from sysbio_modeling_amd import build, models_zoo
+from sysbio_modeling_amd.symbolic import (make_ode_model, make_jit_model, parse_model_file,
+                                          process_model_dict, zoo_model, ZOO_NAMES)
+from sysbio_modeling_amd.symbolic.sympy_tools import _derive_sensitivity_equations
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_parse_sections():
+    md = parse_model_file(models_zoo.MICHAELIS_MENTEN_TEXT)
+    assert list(md['Parameters']) == ['vmax', 'km', 'k_synt_s', 'k_deg_s', 'k_deg_p']
+    assert list(md['Variables']) == ['_s', '_p']
+    assert 'v_conv' in md['Rate Laws']
+    assert list(md['Differential Equations']) == ['d__s', 'd__p']
+
+
+def test_parse_reference_style_function():
+    """The reference writes models as python functions with #*! markers and `d_y` for `_y`
+    (tests/test_utils/simple_model.py:6-23)."""
+    def simple_model(y, t, *args):
+        p = args[0]
+        #*! Parameters Start
+        k_deg = p[0]
+        k_synt = p[1]
+        #*! Parameters End
+        #*! Variables Start
+        _y = y[0]
+        #*! Variables End
+        #*! Differential Equations Start
+        d_y = k_synt - k_deg * _y
+        #*! Differential Equations End
+        return d_y
+    gm = make_ode_model(simple_model, name='fn_style')
+    assert gm.param_order == ['k_deg', 'k_synt'] and gm.n_vars == 1
+    out = np.zeros(3)
+    gm.sens_model(np.array([2.0, 0.5, 0.25]), 0.0, out, np.array([0.1, 3.0]))
+    assert np.allclose(out, [3.0 - 0.2, -2.0 - 0.05, 1.0 - 0.025])
+
+
+def test_rate_laws_substituted():
+    gm = zoo_model('michaelis_menten')
+    y, p = np.array([0.3, 0.7]), np.array([2.0, 0.5, 0.1, 0.2, 0.3])
+    out = np.zeros(2)
+    gm.model(y, 0.0, out, p)
+    v = p[0] * y[0] / (p[1] + y[0])
+    assert np.allclose(out, [p[2] - v - p[3] * y[0], v - p[4] * y[1]])
+
+
+def test_sparse_form_equals_expanded_sensitivity_equations():
+    """S' = J_y S + J_p, printed sparsely, equals the reference's expanded definition
+    d/dt sens_i_j = df_i/dp_j + sum_m df_i/dy_m sens_m_j (symbolic/sympy_tools.py:130-146)."""
+    gm = zoo_model('michaelis_menten')
+    spec = gm.spec
+    params = {p: sympy.Symbol(p) for p in spec.params}
+    expanded = _derive_sensitivity_equations(spec.equations, params)
+    rng = np.random.default_rng(3)
+    n, k = spec.n_vars, spec.n_sens
+    for _ in range(4):
+        y = rng.uniform(0.1, 1.0, n + n * k)
+        p = rng.uniform(0.1, 1.0, len(spec.params))
+        subs = {sympy.Symbol(v): y[i] for i, v in enumerate(spec.variables)}
+        subs.update({sympy.Symbol(q): p[i] for i, q in enumerate(spec.params)})
+        for i, vi in enumerate(spec.variables):
+            for j, pj in enumerate(spec.sens_params):
+                subs[sympy.Symbol('sens_%s_%s' % (vi, pj))] = y[n + i * k + j]
+        want = [float(e.subs(subs)) for e in expanded.values()]
+        out = np.zeros(n + n * k)
+        gm.sens_model(y, 0.0, out, p)
+        assert np.allclose(out[n:], want, rtol=1e-12)
+
+
+def test_fixed_parameters_drop_sensitivity_columns():
+    gm = make_ode_model(models_zoo.MICHAELIS_MENTEN_TEXT, name='mm_fixed', fixed_params=['km'])
+    assert gm.sens_params == ['vmax', 'k_synt_s', 'k_deg_s', 'k_deg_p'] and gm.n_sens == 4
+    full = zoo_model('michaelis_menten')
+    rng = np.random.default_rng(5)
+    y5 = rng.uniform(0.1, 1, 12)
+    p = rng.uniform(0.1, 1, 5)
+    keep = [0, 2, 3, 4]
+    y4 = np.concatenate([y5[:2], y5[2:].reshape(2, 5)[:, keep].ravel()])
+    o5, o4 = np.zeros(12), np.zeros(10)
+    full.sens_model(y5, 0.0, o5, p)
+    gm.sens_model(y4, 0.0, o4, p)
+    assert np.allclose(o4[2:].reshape(2, 4), o5[2:].reshape(2, 5)[:, keep])
+    with pytest.raises(KeyError):
+        process_model_dict(parse_model_file(models_zoo.SIMPLE_MODEL_TEXT), fixed_params=['nope'])
+
+
+def test_make_jit_model_facade_and_output_fh():
+    fh = io.StringIO()
+    fn = make_jit_model(models_zoo.SIMPLE_MODEL_TEXT, fh, calculate_sensitivities=False, name='facade')
+    out = np.zeros(1)
+    fn(np.array([1.0]), 0.0, out, np.array([0.5, 2.0]))
+    assert out[0] == 1.5
+    assert 'def sens_model(y, t, yout, p):' in fh.getvalue()
+
+
+@pytest.mark.parametrize('name', ZOO_NAMES)
+def test_committed_headers_are_current(name):
+    """csrc/models/<name>.hpp is exactly what the emitter prints today (the GPU box builds
+    plugins from the committed text)."""
+    gm = zoo_model(name)
+    with open(os.path.join(build.MODELS_DIR, name + '.hpp')) as fh:
+        assert fh.read() == gm.hip_source
+
+
+@pytest.mark.parametrize('name', ZOO_NAMES)
+def test_hip_text_equals_python_and_c_on_host(name, tmp_path):
+    gm = zoo_model(name)
+    hdr = os.path.join(build.MODELS_DIR, name + '.hpp')
+    so = str(tmp_path / ('h_%s.so' % name))
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-DSBM_MODEL_HEADER="%s"' % hdr,
+                           os.path.join(HERE, 'support', 'host_model_harness.cpp'), '-o', so])
+    lib = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    n, k = gm.n_vars, gm.n_sens
+    assert (lib.h_n_vars(), lib.h_n_params(), lib.h_n_sens()) == (n, len(gm.param_order), k)
+    clib = gm.c_library()
+    rng = np.random.default_rng(11)
+    for _ in range(5):
+        y = rng.uniform(0.05, 2.0, n + n * k)
+        p = rng.uniform(0.05, 2.0, len(gm.param_order))
+        ref = np.zeros(n + n * k)
+        gm.sens_model(y, 0.0, ref, p)
+        for fn in (lib.h_sens_rhs, lib.h_sens_rhs_fused, clib.sbm_sens_rhs):
+            out = np.zeros(n + n * k)
+            fn(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp), p.ctypes.data_as(dp))
+            assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
+        ref_s = np.zeros(n)
+        gm.model(y[:n].copy(), 0.0, ref_s, p)
+        out = np.zeros(n)
+        lib.h_rhs(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp), p.ctypes.data_as(dp))
+        assert np.allclose(out, ref_s, rtol=1e-13, atol=1e-15)
+        assert np.allclose(ref[:n], ref_s, rtol=1e-13, atol=1e-15)
+
+
+def test_cascade_definition():
+    """the synthetic benchmark network."""
+    spec = models_zoo.cascade_spec()
+    assert spec.n_vars == 20 and spec.n_params == 40 and spec.n_sens == 40
+    gm = zoo_model('cascade20')
+    assert len(gm.derived.jy) == 40 and len(gm.derived.jp) == 40   # <= 2 non-zeros per row each
+    p = models_zoo.cascade_nominal_params()
+    assert np.allclose(p[:20], 1.0) and np.allclose(p[20:], 0.1 * (1 + np.arange(20) / 20.0))
+    y = np.linspace(0.1, 2.0, 20)
+    out = np.zeros(20)
+    gm.model(y, 0.0, out, p)
+    assert out[0] == pytest.approx(1.0 / (1 + y[19]) - 0.1 * y[0])
+    assert out[7] == pytest.approx(y[6] / (1 + y[6]) - p[27] * y[7])
+    theta, P = models_zoo.cascade_ensemble(16)
+    assert P.shape == (16, 40) and np.allclose(np.exp(theta), P)
+    theta2, _ = models_zoo.cascade_ensemble(16)
+    assert np.array_equal(theta, theta2)   # seeded
