@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""bench.py -- ensemble ODE-steps/sec of the 20-state / 40-parameter model with forward
+sensitivities (BASELINE.json metric; workload = configs[2], plus the residual/Jacobian
+assembly that consumes it).
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: theta -> p gather, Dormand-Prince 5(4) integration of the 820-equation
+augmented system for 4096 parameter vectors (per GPU), and the fused sample + residual +
+Jacobian assembly of a one-experiment Project on top (64 rows x 40 parameters per vector).
+value = accepted integrator steps of all trajectories of all ranks / wall time.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: the ensemble is sharded by vector index (weak scaling: 4096 vectors per GPU, no
+data-path collective); RCCL carries only the all-gather of the per-vector residual norms.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_AUG = 820                  # 20 + 20*40 coupled ODEs
+BYTES_PER_STEP = 2 * 8 * N_AUG   # read + write the augmented state once per step
+V_PER_GPU = 4096
+
+
+def build_workload(model, gm, n_vectors, rank):
+    """configs[2] as a Project: one experiment, species 4/9/14/19 measured at 16 times."""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    import warnings
+    # synthetic data: nominal trajectory x (1 + 5 % noise), seed 7; generated ON THE GPU PATH
+    # (bench inputs must not depend on the oracle)
+    p_nom = models_zoo.cascade_nominal_params()
+    grid = np.linspace(0, models_zoo.CASCADE_T_END, 1000)
+    idx = np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)
+    y = model.simulate(p_nom, np.concatenate([[0.0], grid[idx]]))[1:]
+    rng = np.random.default_rng(7)
+    ms = []
+    for v in models_zoo.CASCADE_MEASURED_SPECIES:
+        data = y[:, v] * (1.0 + 0.05 * rng.standard_normal(len(idx)))
+        ms.append(TimecourseMeasurement('s%d' % v, data, models_zoo.CASCADE_MEASURE_TIMES.copy(),
+                                        0.05 * np.abs(data) + 0.01))
+    exp = Experiment('exp_0', ms)
+    mapping = {('s%d' % v): ('direct', v) for v in models_zoo.CASCADE_MEASURED_SPECIES}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        proj = Project(model, [exp], {'Global': list(gm.param_order)}, mapping,
+                       sf_groups=['s%d' % v for v in models_zoo.CASCADE_MEASURED_SPECIES])
+    # global ensemble of world*4096 vectors; this rank owns a contiguous block
+    theta_all, _ = models_zoo.cascade_ensemble(n_vectors * (rank + 1))
+    theta = theta_all[rank * n_vectors:(rank + 1) * n_vectors]
+    # project vector order == model order here (all Global, listed in model order)
+    order = [gm.param_order.index(name) for name, _ in proj.get_ordered_project_params()]
+    return proj, np.ascontiguousarray(theta[:, order]), grid[idx]
+
+
+def cpu_baseline(gm, theta_rows, budget_s=12.0, max_vectors=4096):
+    """The oracle (SciPy odeint restatement of OdeModel.calc_jacobian, compiled C RHS standing in
+    for the reference's numba) timed on ONE host core over a bounded sample of the same ensemble."""
+    from oracle import odeint_oracle as oo
+    grid = np.linspace(0, 100.0, 1000)
+    steps, n, t0 = 0, 0, time.perf_counter()
+    gm.c_library()
+    for row in theta_rows[:max_vectors]:
+        _, info = oo.calc_jacobian(gm, np.exp(row), grid, use_c=True, full_output=True)
+        steps += int(info['nst'][-1])
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "ODE-steps/s", "cores": 1, "kind": "port",
+            "sample": "first %d vectors of the ensemble, state+sensitivity system (820 ODEs), "
+                      "scipy.integrate.odeint rtol=atol=1e-10 on the reference's 1000-point grid, "
+                      "compiled C RHS; %.1f s, %d LSODA steps" % (n, dt, steps),
+            "ms_per_vector": 1e3 * dt / max(n, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--vectors', type=int, default=V_PER_GPU, help="parameter vectors per GPU")
+    ap.add_argument('--method', default='dopri45', choices=['dopri45', 'rk4'])
+    ap.add_argument('--rk4-steps', type=int, default=4096)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from sysbio_modeling_amd import _lib
+    from sysbio_modeling_amd.symbolic import zoo_model
+    from sysbio_modeling_amd.model import OdeModel
+    gm = zoo_model('cascade20')
+    model = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, use_jit=False)
+    model.enable_jit(_lib.Context(local_rank))
+    V = args.vectors
+    proj, theta, t_meas = build_workload(model, gm, V, rank)
+    lib = _lib.load_library()
+    pj = proj._device()
+    q, R, G = proj.n_project_params, proj.n_project_residuals, 4
+    f64, i32 = torch.float64, torch.int32
+    th = torch.from_numpy(theta).to(dev)
+    out = dict(sims=torch.empty((V, R), dtype=f64, device=dev), res=torch.empty((V, R), dtype=f64, device=dev),
+               J=torch.empty((V, R, q), dtype=f64, device=dev), sf=torch.empty((V, G), dtype=f64, device=dev),
+               norms=torch.empty((V,), dtype=f64, device=dev), status=torch.empty((V,), dtype=i32, device=dev),
+               nsteps=torch.empty((V,), dtype=i32, device=dev))
+    gathered = torch.empty((world * V,), dtype=f64, device=dev) if world > 1 else None
+    if args.method == 'dopri45':
+        opts = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+    else:
+        opts = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0)
+    p = _lib.dev_ptr
+
+    def step():
+        _lib.check(lib.sbm_jacobian_batch(pj, p(th), V, ctypes.byref(opts), p(out['sims']), p(out['res']),
+                                          p(out['J']), None, p(out['sf']), None, p(out['norms']), None,
+                                          p(out['status']), p(out['nsteps'])), 'sbm_jacobian_batch')
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out['norms'])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    steps_per_pass = int(out['nsteps'].sum().item())
+    n_bad = int((out['status'] != 0).sum().item())
+    stats = torch.tensor([dt, float(steps_per_pass), float(n_bad)], dtype=f64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, total_steps_per_pass, n_bad = float(mx[0]), float(sm[1]), int(sm[2])
+    else:
+        total_steps_per_pass = float(steps_per_pass)
+    value = total_steps_per_pass * args.steps / dt
+
+    # ---- roofline of the dominant kernel: the sensitivity integrator alone, HIP events on its stream ----
+    dm = model.device_model
+    theta_p = torch.exp(th)  # all parameters Global and in model order: p = exp(theta)
+    tg = torch.from_numpy(np.concatenate([[0.0], t_meas])).to(dev)
+    Yk = torch.empty((V, len(tg), 20), dtype=f64, device=dev)
+    Sk = torch.empty((V, len(tg), 20, 40), dtype=f64, device=dev)
+    ns_k = torch.empty((V,), dtype=i32, device=dev)
+    for _ in range(max(1, args.warmup)):
+        dm.sens_dev(theta_p, tg, None, opts, Yk, Sk, None, ns_k, None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(args.steps):
+        dm.sens_dev(theta_p, tg, None, opts, Yk, Sk, None, ns_k, None)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    k_ms = e0.elapsed_time(e1) / args.steps
+    k_steps = int(ns_k.sum().item())
+    achieved = k_steps * BYTES_PER_STEP / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh).get(args.method, {}).get('hbm_bytes_per_launch')
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "sbm_sens_kernel<cascade20,%s>" % args.method, "kernel_ms": k_ms,
+                "steps_per_launch": k_steps, "algorithmic_bytes_per_step": BYTES_PER_STEP,
+                "kernel_steps_per_s": k_steps / (k_ms * 1e-3),
+                "note": "algorithmic bytes (2*8*820 B per accepted step) / kernel time; the kernel keeps the "
+                        "state in VGPRs, so real HBM traffic ('traffic') is far below this figure"}
+
+    extras = {}
+    if not args.no_extras and rank == 0:
+        def time_kernel(kind, o, reps=3):
+            for _ in range(1):
+                (dm.sens_dev(theta_p, tg, None, o, Yk, Sk, None, ns_k, None) if kind == 'sens'
+                 else dm.simulate_dev(theta_p, tg, None, o, Yk, None, ns_k, None))
+            torch.cuda.synchronize(dev)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                (dm.sens_dev(theta_p, tg, None, o, Yk, Sk, None, ns_k, None) if kind == 'sens'
+                 else dm.simulate_dev(theta_p, tg, None, o, Yk, None, ns_k, None))
+            b.record()
+            torch.cuda.synchronize(dev)
+            ms = a.elapsed_time(b) / reps
+            st = int(ns_k.sum().item())
+            return {"ms": ms, "steps": st, "steps_per_s": st / (ms * 1e-3)}
+        rk = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0)
+        dp = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+        extras = {"sens_rk4_fixed_%d" % args.rk4_steps: time_kernel('sens', rk),
+                  "sens_dopri45": time_kernel('sens', dp),
+                  "state_only_dopri45_configs1": time_kernel('state', dp),
+                  "state_only_rk4_fixed_%d" % args.rk4_steps: time_kernel('state', rk)}
+
+    result = {
+        "metric": "ensemble ODE-steps/sec (20-state model + fwd sens)",
+        "value": value, "unit": "ODE-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[2]: cascade20 (20 states, 40 params) with full forward sensitivities "
+                               "(820 coupled ODEs), %d parameter vectors per GPU, %s; step = theta->p gather + "
+                               "integration + fused residual/Jacobian assembly (64 rows x 40 params, 4 scale "
+                               "factors)%s" % (V, "DOPRI45 rtol=1e-9 atol=1e-12, 16 output times"
+                                               if args.method == 'dopri45' else "RK4 fixed, %d steps" % args.rk4_steps,
+                                               " + RCCL all-gather of residual norms" if world > 1 else ""),
+                   "vectors_per_gpu": V, "n_equations": N_AUG, "integrator": args.method,
+                   "accepted_steps_per_pass": total_steps_per_pass, "failed_vectors": n_bad},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(gm, theta)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if extras:
+        result["extras"] = extras
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   double* s_sde = s_B + (G > 0 ? G : 1);
   double* s_sds = s_sde + (G > 0 ? G : 1);
   double* s_red = s_sds + (G > 0 ? G : 1);  // [4]
-  double* s_dB = s_red + 4;                 // [2][G][q]
+  double* s_dB = s_red + 4;                 // [G][q], then the partial sums [2][G][rpp][q]
   __shared__ int s_bad;
 
   if (tid == 0) s_bad = 0;
@@ -494,14 +494,16 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   double* Jv = a.J ? a.J + (size_t)v * RT * q : nullptr;
   double* Jm = a.Jmodel ? a.Jmodel + (size_t)v * R * q : nullptr;
   const double* th = a.Theta + (size_t)v * q;
-  double* s_jde = s_dB;                       // [G][q]  becomes dB/dtheta
-  double* s_jds = s_dB + (size_t)(G > 0 ? G : 1) * q;  // [G][q]
-  for (int i = tid; i < 2 * (G > 0 ? G : 1) * q; i += blockDim.x) s_dB[i] = 0.0;
-  __syncthreads();
-
+  // partial sums owned by ONE thread each, [which][g][row lane][c]: no atomics, and the final
+  // reduction runs in a fixed order, so results are bitwise reproducible run to run
   const int nthr = blockDim.x;
   const int cw = q < nthr ? q : nthr;  // columns handled side by side (consecutive threads -> consecutive columns)
   const int rpp = nthr / cw;           // row lanes
+  const int Gn = G > 0 ? G : 1;
+  double* s_part = s_dB + (size_t)Gn * q;  // [2][Gn][rpp][q]
+  for (int i = tid; i < 2 * Gn * rpp * q; i += nthr) s_part[i] = 0.0;
+  __syncthreads();
+
   const int cl = tid % cw, rl = tid / cw;
   for (int c0 = 0; c0 < q; c0 += cw) {
     const int c = c0 + cl;
@@ -524,7 +526,10 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
       if (Jv) Jv[(size_t)r * q + c] = jm;
       const int g = a.row_sf[r];
       if (g != gcur) {  // rows of one group are mostly consecutive: flush on change
-        if (gcur >= 0) { atomicAdd(&s_jde[gcur * q + c], jde); atomicAdd(&s_jds[gcur * q + c], jds); }
+        if (gcur >= 0) {
+          s_part[((size_t)(0 * Gn + gcur) * rpp + rl) * q + c] += jde;
+          s_part[((size_t)(1 * Gn + gcur) * rpp + rl) * q + c] += jds;
+        }
         gcur = g; jde = 0.0; jds = 0.0;
       }
       if (g >= 0) {
@@ -533,14 +538,22 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
         jds += jm * s_sim[r] * w;
       }
     }
-    if (gcur >= 0) { atomicAdd(&s_jde[gcur * q + c], jde); atomicAdd(&s_jds[gcur * q + c], jds); }
+    if (gcur >= 0) {
+      s_part[((size_t)(0 * Gn + gcur) * rpp + rl) * q + c] += jde;
+      s_part[((size_t)(1 * Gn + gcur) * rpp + rl) * q + c] += jds;
+    }
   }
   __syncthreads();
   // dB_g/dtheta_c = jde/sds - 2 sde jds / sds^2   (linear_scale_factor.py:33-42)
-  for (int i = tid; i < G * q; i += blockDim.x) {
-    const int g = i / q;
+  for (int i = tid; i < G * q; i += nthr) {
+    const int g = i / q, c = i - g * q;
+    double jde = 0.0, jds = 0.0;
+    for (int l = 0; l < rpp; ++l) {
+      jde += s_part[((size_t)(0 * Gn + g) * rpp + l) * q + c];
+      jds += s_part[((size_t)(1 * Gn + g) * rpp + l) * q + c];
+    }
     const double sds = s_sds[g], sde = s_sde[g];
-    const double db = s_jde[i] / sds - 2.0 * sde * s_jds[i] / (sds * sds);
+    const double db = jde / sds - 2.0 * sde * jds / (sds * sds);
     s_dB[i] = db;
     if (a.sf_grad) a.sf_grad[(size_t)v * G * q + i] = db;
   }
@@ -763,7 +776,8 @@ static int project_run(sbm_project* p, const double* Theta, int V, const sbm_int
   g.J = sens ? J : nullptr; g.Jmodel = sens ? Jmodel : nullptr; g.grad = sens ? grad : nullptr;
   g.sf_grad = sens ? sf_grad : nullptr;
   const int Gn = p->G > 0 ? p->G : 1;
-  const size_t lds = sizeof(double) * ((size_t)2 * p->R + 3 * Gn + 4 + (size_t)2 * Gn * p->q);
+  const int cw_ = p->q < 256 ? p->q : 256, rpp_ = 256 / cw_;
+  const size_t lds = sizeof(double) * ((size_t)2 * p->R + 3 * Gn + 4 + (size_t)Gn * p->q + (size_t)2 * Gn * rpp_ * p->q);
   if (lds > 160 * 1024) return sbm_fail(SBM_E_ARG, "%s: project too large for the assembly kernel (%zu B of LDS)", who, lds);
   if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_assemble, dim3(V), dim3(256), lds, s, g);
