@@ -221,8 +221,12 @@ def main():
             return {"ms": ms, "steps": st, "steps_per_s": st / (ms * 1e-3)}
         rk = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0)
         dp = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+        dp_pw = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant='per_wave')
+        rk_pw = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0, variant='per_wave')
         extras = {"sens_rk4_fixed_%d" % args.rk4_steps: time_kernel('sens', rk),
                   "sens_dopri45": time_kernel('sens', dp),
+                  "sens_dopri45_per_wave_variant": time_kernel('sens', dp_pw),
+                  "sens_rk4_fixed_%d_per_wave_variant" % args.rk4_steps: time_kernel('sens', rk_pw),
                   "state_only_dopri45_configs1": time_kernel('state', dp),
                   "state_only_rk4_fixed_%d" % args.rk4_steps: time_kernel('state', rk)}
 

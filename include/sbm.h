@@ -50,7 +50,17 @@ typedef struct sbm_integrator_opts {
   double t0;         /* time of the initial condition; output times must be >= t0.
                       * odeint takes t_sim[0] for it (model/ode_model.py:122,167);
                       * Project always integrates from 0 (base_project.py:419)     */
+  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE    */
+  int32_t reserved;  /* must be 0                                                       */
 } sbm_integrator_opts;
+
+/* Two implementations of the sensitivity integrator with identical results up to
+ * rounding, both one trajectory per wavefront and one sensitivity column per lane:
+ * PER_WAVE evaluates f / J_y / J_p on every lane from broadcast operands; ROW_LANE
+ * evaluates them once, lane i working on row i (rows of the same kinetic form side
+ * by side), and hands them to the columns through LDS.  ROW_LANE needs n_vars <= 64
+ * and n_sens <= 64; AUTO picks it when the model's rows fall into few classes. */
+enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2 };
 
 /* per-trajectory status written next to the results (the reference does not
  * check LSODA failures, model/ode_model.py:122,167; non-zero statuses are what

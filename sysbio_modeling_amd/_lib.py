@@ -25,7 +25,7 @@ class SbmError(RuntimeError):
 class IntegratorOpts(ctypes.Structure):
     _fields_ = [('method', ctypes.c_int32), ('max_steps', ctypes.c_int32),
                 ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double),
-                ('t0', ctypes.c_double)]
+                ('t0', ctypes.c_double), ('variant', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class ProjectDesc(ctypes.Structure):
@@ -115,7 +115,11 @@ def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None, t0=0.0):
+VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2}
+
+
+def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None, t0=0.0,
+              variant='auto'):
     """IntegratorOpts from keywords.  For 'rk4' give h0 or (n_steps, t_end)."""
     if isinstance(method, str):
         key = method.lower()
@@ -131,7 +135,8 @@ def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_st
         if n_steps is None or t_end is None:
             raise ValueError("rk4 needs h0, or n_steps together with t_end")
         h0 = (float(t_end) - float(t0)) / int(n_steps)
-    return IntegratorOpts(m, int(max_steps), float(rtol), float(atol), float(h0), float(t0))
+    v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    return IntegratorOpts(m, int(max_steps), float(rtol), float(atol), float(h0), float(t0), v, 0)
 
 
 # ---------------------------------------------------------------------------

@@ -93,9 +93,11 @@ constexpr double E1 = 71.0 / 57600.0, E3 = -71.0 / 16695.0, E4 = 71.0 / 1920.0, 
                  E6 = 22.0 / 525.0, E7 = -1.0 / 40.0;
 }  // namespace dp
 
+// every element a lane integrates: CPL columns of NV rows, plus NX extra scalars per lane
+// (row-lane kernel: the lane's own state component)
 #define SBM_ALL(c, i)                       \
   _Pragma("unroll") for (int c = 0; c < CPL; ++c) \
-  _Pragma("unroll") for (int i = 0; i < NV; ++i)
+  _Pragma("unroll") for (int i = 0; i < NVX; ++i)
 
 // ---------------------------------------------------------------------------
 // "System" policies: what differs between the two mappings
@@ -109,6 +111,7 @@ struct SbmLdsParams {  // [param][lane] image in LDS
 template <class M>
 struct SensSystem {
   static constexpr int NV = M::NV;
+  static constexpr int NVX = M::NV;   // no extra per-lane elements
   static constexpr int NCOL = 1 + M::NK;
   static constexpr int CPL = (NCOL + 63) / 64;
   static constexpr bool kUniform = true;
@@ -134,7 +137,7 @@ struct SensSystem {
   }
   // error norm: max over columns of the column's RMS (every column, the state
   // included, individually meets the tolerance -- the CVODES-style sens. test)
-  __device__ __forceinline__ float norm(const float (&colsum)[CPL]) const {
+  __device__ __forceinline__ float norm(const float (&colsum)[CPL], float /*xsum*/) const {
     float m = 0.f;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) m = sbm_nanmax(m, colsum[c]);
@@ -151,6 +154,7 @@ struct SensSystem {
 template <class M>
 struct StateSystem {
   static constexpr int NV = M::NV;
+  static constexpr int NVX = M::NV;
   static constexpr int CPL = 1;
   static constexpr bool kUniform = false;
   SbmLdsParams p;
@@ -158,7 +162,9 @@ struct StateSystem {
   __device__ __forceinline__ void rhs(double t, const double (&z)[1][NV], double (&dz)[1][NV]) const {
     M::eval_f(t, z[0], p, dz[0]);
   }
-  __device__ __forceinline__ float norm(const float (&colsum)[1]) const { return sqrtf(colsum[0] * (1.0f / NV)); }
+  __device__ __forceinline__ float norm(const float (&colsum)[1], float /*xsum*/) const {
+    return sqrtf(colsum[0] * (1.0f / NV));
+  }
   __device__ __forceinline__ double sum(double v) const { return v; }
 };
 
@@ -176,16 +182,17 @@ struct SbmTrajOut {
 // grid points, project/utils.py:18-21 -- no dense output, no interpolation).
 // `Store` is called as store(io, z) once per output index.
 template <class Sys, class Store>
-__device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sys::CPL][Sys::NV],
+__device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sys::CPL][Sys::NVX],
                                                    const double* __restrict__ t_out, int n_t,
                                                    const sbm_integrator_opts& o, Store&& store) {
   constexpr int NV = Sys::NV;
+  constexpr int NVX = Sys::NVX;
   constexpr int CPL = Sys::CPL;
   using namespace dp;
   const double rtol = o.rtol, atol = o.atol;
   const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000;
 
-  double k1[CPL][NV], k2[CPL][NV], k3[CPL][NV], k4[CPL][NV], k5[CPL][NV], k6[CPL][NV], zt[CPL][NV];
+  double k1[CPL][NVX], k2[CPL][NVX], k3[CPL][NVX], k4[CPL][NVX], k5[CPL][NVX], k6[CPL][NVX], zt[CPL][NVX];
   double t = o.t0;
   SbmTrajOut out{SBM_OK, 0, 0};
   if (n_t <= 0) return out;
@@ -267,20 +274,29 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       // embedded error estimate; ratios and norm in f32 (they only steer the controller)
       const double he1 = hs * E1, he3 = hs * E3, he4 = hs * E4, he5 = hs * E5, he6 = hs * E6, he7 = hs * E7;
       float colsum[CPL];
+      float xsum = 0.f;
+      auto err_ratio = [&](int c, int i) {
+        const double e = fma(he7, k2[c][i],
+                             fma(he6, k6[c][i], fma(he5, k5[c][i], fma(he4, k4[c][i], fma(he3, k3[c][i], he1 * k1[c][i])))));
+        const double sc = fma(rtol, fmax(fabs(z[c][i]), fabs(zt[c][i])), atol);
+        return (float)e * __builtin_amdgcn_rcpf((float)sc);
+      };
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          const double e = fma(he7, k2[c][i],
-                               fma(he6, k6[c][i], fma(he5, k5[c][i], fma(he4, k4[c][i], fma(he3, k3[c][i], he1 * k1[c][i])))));
-          const double sc = fma(rtol, fmax(fabs(z[c][i]), fabs(zt[c][i])), atol);
-          const float r = (float)e * __builtin_amdgcn_rcpf((float)sc);
+          const float r = err_ratio(c, i);
           acc = fmaf(r, r, acc);
         }
         colsum[c] = acc;
+#pragma unroll
+        for (int i = NV; i < NVX; ++i) {
+          const float r = err_ratio(c, i);
+          xsum = fmaf(r, r, xsum);
+        }
       }
-      const float err = sys.norm(colsum);
+      const float err = sys.norm(colsum, xsum);
 
       const bool finite = (err == err) && (err < 3.0e38f);
       const bool accept = finite && (err <= 1.0f);
@@ -318,12 +334,12 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
 
 // classic RK4, fixed step: every output interval is cut into ceil(dt / h0) equal steps
 template <class Sys, class Store>
-__device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::CPL][Sys::NV],
+__device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::CPL][Sys::NVX],
                                                const double* __restrict__ t_out, int n_t,
                                                const sbm_integrator_opts& o, Store&& store) {
-  constexpr int NV = Sys::NV;
+  constexpr int NVX = Sys::NVX;
   constexpr int CPL = Sys::CPL;
-  double k[CPL][NV], acc[CPL][NV], zt[CPL][NV];
+  double k[CPL][NVX], acc[CPL][NVX], zt[CPL][NVX];
   SbmTrajOut out{SBM_OK, 0, 0};
   const double h0 = o.h0;
   const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000000;
@@ -479,6 +495,152 @@ __global__ void __launch_bounds__(64) sbm_state_kernel(sbm_kernel_args a) {
   if (a.n_reject) a.n_reject[traj] = r.n_rej;
 }
 
+// ===========================================================================
+// Row-lane sensitivity kernel: SIMD across isomorphic equations.
+//
+// Still one trajectory per wavefront and one sensitivity column per lane (lane j owns column j
+// of S, all NV rows, every Runge-Kutta stage in VGPRs).  What changes is who evaluates the part
+// of the right-hand side that is identical for all columns.  The per-wave kernel above computes
+// f, J_y and J_p on all 64 lanes from broadcast operands, then every lane picks "its" J_p entry
+// with v_cndmask chains: rocprofv3 shows it VALU-issue bound (one wave per SIMD issues one
+// instruction per ~4 cycles whatever its type) with ~60 % of the instructions spent there.
+// Here
+//   * the state itself lives one component per lane (lane i integrates y_i as an extra
+//     element next to its column), so publishing a stage state is ONE ds_write per lane;
+//   * rows with the same kinetic form (emit_rowlane.py) are evaluated together, lane i
+//     computing f_i and the J_y / J_p entries of row i from per-lane operands (its parameters
+//     sit in registers for the whole kernel, its state operands come from LDS by index);
+//   * each row lane drops its J_y entries into a list and its J_p entries into the additive
+//     matrix A[NV][64] in LDS, and every column lane then evaluates the same
+//     dz_i = sum_m J_y[i,m] z_m + A[i][lane]  -- J_y broadcast reads, A one column per lane
+//     (conflict-free), no selects, no readfirstlane.
+// Only wave-local ordering is needed (a 64-thread workgroup): no cross-wave barrier anywhere.
+// ===========================================================================
+template <class M>
+struct SbmRowLaneShared {
+  double Y[64];                 // stage state, one component per row lane
+  double JY[M::NJY + 2];        // J_y non-zeros (+ a spare slot for unused outputs)
+  double A[M::NV * 64 + 2];     // A[i][c] = J_p[i][c]; zero where J_p is structurally zero
+};
+
+template <class M>
+struct RowLaneSystem {
+  static constexpr int NV = M::NV;
+  static constexpr int NVX = M::NV + 1;  // column rows + this lane's own state component
+  static constexpr int CPL = 1;
+  SbmRowLaneShared<M>* sh;
+  int lane;
+  int cls;                       // class of this lane's row, -1 on lanes without a row
+  int yidx[M::RL_MAXYS];         // which state feeds operand slot s
+  double ps[M::RL_MAXPS];        // this row's parameters
+  int jyout[M::RL_MAXJY];        // where this row's J_y entries go
+  int apos[M::RL_MAXJP];         // where this row's J_p entries go in A
+
+  __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
+    sh->Y[lane] = z[0][NV];
+    __syncthreads();  // one wave per workgroup: this orders the LDS traffic, it is not a cross-wave barrier
+    double ys[M::RL_MAXYS];
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXYS; ++s) ys[s] = sh->Y[yidx[s]];
+    double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
+    M::class_dispatch(cls, t, ys, ps, f, jy, jp);
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) sh->JY[jyout[s]] = jy[s];
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
+    __syncthreads();
+    double zc[NV], dc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) zc[i] = z[0][i];
+    M::apply_rowlane(sh->JY, &sh->A[lane], zc, dc);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
+    dz[0][NV] = f;
+    __syncthreads();  // the next stage overwrites Y / JY / A: keep this stage's reads ahead of it
+  }
+  // max( RMS of the state error, max over columns of the column RMS ): the same test as the
+  // per-wave kernel, with the state spread over the lanes
+  __device__ __forceinline__ float norm(const float (&colsum)[1], float xsum) const {
+    const float m = colsum[0];
+    const float bad = (m != m || xsum != xsum) ? 1.f : 0.f;
+    const float mx = sbm_wave_max((m != m) ? 0.f : m);
+    float xs = (xsum != xsum) ? 0.f : xsum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) xs += __shfl_xor(xs, off, 64);
+    xs = sbm_bcast0f(xs);
+    const float anybad = sbm_wave_max(bad);
+    return anybad > 0.f ? __builtin_nanf("") : sqrtf(fmaxf(mx, xs) * (1.0f / NV));
+  }
+  __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
+};
+
+template <class M, int METHOD>
+__global__ void __launch_bounds__(64) sbm_sens_rowlane_kernel(sbm_kernel_args a) {
+  using Sys = RowLaneSystem<M>;
+  constexpr int NV = M::NV;
+  constexpr int NVX = NV + 1;
+  constexpr int NK = M::NK;
+  static_assert(NV <= 64 && NK <= 64, "row-lane kernel: one row and one column per lane");
+  __shared__ SbmRowLaneShared<M> sh;
+  const int traj = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (traj >= a.n_traj) return;
+
+  for (int i = lane; i < NV * 64 + 2; i += 64) sh.A[i] = 0.0;
+  for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
+  sh.Y[lane] = 0.0;
+
+  Sys sys;
+  sys.sh = &sh;
+  sys.lane = lane;
+  const bool has_row = lane < NV;
+  const int row = has_row ? lane : 0;
+  sys.cls = has_row ? M::rl_class(row) : -1;
+  const double* P = a.P + (size_t)traj * M::NP;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[s] = M::rl_ys(s, row);
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[s] = P[M::rl_ps(s, row)];
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJY; ++s) sys.jyout[s] = has_row ? M::rl_jyout(s, row) : M::NJY + 1;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJP; ++s) sys.apos[s] = has_row ? M::rl_apos(s, row) : NV * 64 + 1;
+  __syncthreads();
+
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+
+  double z[1][NVX];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) z[0][i] = (a.s0 && lane < NK) ? a.s0[i * NK + lane] : 0.0;
+  z[0][NV] = (a.y0 && has_row) ? a.y0[lane] : 0.0;
+
+  double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
+  double* St = a.S ? a.S + (size_t)traj * a.n_t * NV * NK : nullptr;
+  auto store = [&](int io, const double (&zz)[1][NVX]) {
+    if (Yt && has_row) Yt[(size_t)io * NV + lane] = zz[0][NV];
+    if (St && lane < NK) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + lane] = zz[0][i];
+    }
+  };
+
+  SbmTrajOut r;
+  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
+  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+
+  if (lane == 0) {
+    if (a.status) a.status[traj] = r.status;
+    if (a.n_steps) a.n_steps[traj] = r.n_acc;
+    if (a.n_reject) a.n_reject[traj] = r.n_rej;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host-side launcher used by sbm_plugin_main.hip
 // ---------------------------------------------------------------------------
@@ -487,6 +649,22 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
   const sbm_kernel_args a = *args;
   if (a.n_traj <= 0) return (int)hipSuccess;
   if (kind == SBM_KIND_SENS) {
+    // row-lane kernel whenever the model fits one row + one column per lane and its rows fall into
+    // few enough classes to pay (otherwise every class runs alone on a handful of lanes)
+    constexpr bool kRowLaneOk = (M::NV <= 64 && M::NK <= 64);
+    constexpr bool kRowLanePays = kRowLaneOk && (M::RL_NCLASS * 4 <= M::NV + 3);
+    const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
+                         (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays);
+    if constexpr (kRowLaneOk) {
+      if (rowlane) {
+        dim3 grid(a.n_traj), block(64);
+        if (a.opts.method == SBM_DOPRI45)
+          hipLaunchKernelGGL((sbm_sens_rowlane_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+        else
+          hipLaunchKernelGGL((sbm_sens_rowlane_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+        return (int)hipGetLastError();
+      }
+    }
     dim3 grid(a.n_traj), block(64);
     if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);

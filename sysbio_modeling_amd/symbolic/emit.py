@@ -21,6 +21,7 @@ from sympy import Symbol, cse
 from sympy.printing.c import C99CodePrinter
 
 from . import sympy_tools
+from . import emit_rowlane
 
 
 _RCP = sympy.Function('SBM_RCP')
@@ -128,6 +129,10 @@ class Derived:
         self.repl_all, red_all = cse(all_exprs, symbols=sympy.numbered_symbols('x_'),
                                      optimizations='basic')
         n = len(f_exprs)
+        # canonical (pre-CSE) forms, re-CSE'd per row block by the cooperative kernel's emitter
+        self.f_c = all_exprs[:n]
+        self.jy_c = all_exprs[n:n + len(jy)]
+        self.jp_c = all_exprs[n + len(jy):]
         self.f_red = red_all[:n]
         self.jy_red = red_all[n:n + len(jy)]
         self.jp_red = red_all[n + len(jy):]
@@ -328,7 +333,8 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     pr = _ExprPrinter(_symbol_map(spec), rcp="SBM_RCP(%s)", lang='hip')
     nnz_y, nnz_p = max(len(d.jy), 1), max(len(d.jp), 1)
     L = _fmt_header(spec, "//")
-    L += ["#pragma once", "",
+    rl_tables, rl_meta = emit_rowlane.emit_rowlane_tables(spec, d, None)
+    L += ["#pragma once", ""] + rl_tables + [
           "struct SbmModel {",
           "  static constexpr int NV = %d;      // state variables" % n,
           "  static constexpr int NP = %d;      // model parameters (length of p)" % spec.n_params,
@@ -411,5 +417,10 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
         for e_idx, c in d.jy_rows[i]:
             expr = "fma(%s, z[%d], %s)" % (pr.doprint(d.jy_red[e_idx]), c, expr)
         L.append("    dz[%d] = SBM_SEL(state_lane, %s, %s);" % (i, pr.doprint(d.f_red[i]), expr))
-    L += ["  }", "};", ""]
+    L += ["  }", ""]
+
+    # ---- row-lane form: SIMD across isomorphic equations (emit_rowlane.py) ----
+    L += emit_rowlane.emit_rowlane_members(spec, d, rl_meta,
+                                           lambda smap: _ExprPrinter(smap, rcp="SBM_RCP(%s)", lang='hip'))
+    L += ["};", ""]
     return "\n".join(L)

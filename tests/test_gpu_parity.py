@@ -80,6 +80,39 @@ def test_golden_cascade20(gpu_models, golden, method, kw):
     assert np.all(Y2[:, 0] == 0) and np.all(S[:, 0] == 0)     # initial condition row is returned untouched
 
 
+@pytest.mark.parametrize('method,kw', [('dopri45', {}), ('rk4', {'n_steps': 4096})])
+def test_kernel_variants_agree(gpu_models, golden, method, kw):
+    """The per-wave kernel and the row-lane kernel integrate the same
+    equations; both match the reference golden and differ from each other only by rounding.
+    7 vectors: 7 vectors: an odd batch."""
+    from sysbio_modeling_amd import models_zoo
+    m = gpu_models('cascade20')
+    _, P = models_zoo.cascade_ensemble(7)
+    g = golden('cascade20_ref.npz')
+    assert np.array_equal(P[:4], g['P'])
+    t_out = _from_zero(g['t'][g['idx']])
+    res = {}
+    for variant in ('per_wave', 'row_lane'):
+        S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method=method, variant=variant, **kw)
+        assert m.last_info['status'].tolist() == [0] * 7
+        res[variant] = (Y, S, m.last_info['n_steps'].copy())
+        if method == 'dopri45':
+            assert parity_err(Y[:4, 1:], g['Y']) <= 1.0 and parity_err(S[:4, 1:], g['S']) <= 1.0
+    Ya, Sa, na = res['per_wave']
+    Yb, Sb, nb = res['row_lane']
+    assert np.allclose(Ya, Yb, rtol=1e-9, atol=1e-11) and np.allclose(Sa, Sb, rtol=1e-9, atol=1e-10)
+    assert np.all(np.abs(na - nb) <= 2)          # same controller, same step sequence up to rounding
+    # failures stay per trajectory
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Pbad = P.copy()
+        Pbad[2, 5] = np.nan
+        S = m.calc_jacobian_batch(Pbad, t_out, method=method, variant='row_lane', **kw)
+    assert m.last_info['status'][2] != 0 and np.all(np.isnan(S[2, -1]))
+    ok = [0, 1, 3, 4, 5, 6]
+    assert m.last_info['status'][ok].tolist() == [0] * 6 and np.array_equal(S[ok], Sb[ok])
+
+
 def test_live_oracle_random_vectors(gpu_models, zoo):
     from oracle import odeint_oracle as oo
     from sysbio_modeling_amd import models_zoo

@@ -134,7 +134,7 @@ def test_hip_text_equals_python_and_c_on_host(name, tmp_path):
         p = rng.uniform(0.05, 2.0, len(gm.param_order))
         ref = np.zeros(n + n * k)
         gm.sens_model(y, 0.0, ref, p)
-        for fn in (lib.h_sens_rhs, lib.h_sens_rhs_fused, clib.sbm_sens_rhs):
+        for fn in (lib.h_sens_rhs, lib.h_sens_rhs_fused, lib.h_sens_rhs_rowlane, clib.sbm_sens_rhs):
             out = np.zeros(n + n * k)
             fn(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp), p.ctypes.data_as(dp))
             assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
