@@ -71,6 +71,11 @@ def plugin_path(name):
 def build_plugin(name, header_path, force=False, extra_flags=()):
     """sbm_model_<name>.so from a generated model header."""
     os.makedirs(BUILD_DIR, exist_ok=True)
+    # developer A/B builds: SBM_PLUGIN_FLAGS="-DFOO=1" compiles a separately named plugin
+    env_flags = tuple(os.environ.get('SBM_PLUGIN_FLAGS', '').split())
+    if env_flags:
+        name = name + '_' + hashlib.sha1(' '.join(env_flags).encode()).hexdigest()[:8]
+        extra_flags = tuple(extra_flags) + env_flags
     out = plugin_path(name)
     srcs = [header_path, os.path.join(CSRC_DIR, 'sbm_plugin_main.hip'),
             os.path.join(CSRC_DIR, 'sbm_integrators.hpp'), os.path.join(CSRC_DIR, 'sbm_plugin.h'),

@@ -54,6 +54,13 @@ __device__ __forceinline__ double sbm_pick(int scol, int c, double v, double oth
 #define SBM_PICK(scol, c, v, otherwise) sbm_pick(scol, c, v, otherwise)
 __device__ __forceinline__ double sbm_sel(bool c, double a, double b) { return c ? a : b; }
 #define SBM_SEL(c, a, b) sbm_sel(c, a, b)
+// value of `v` in lane `src` (compile-time constant) as a wave-uniform scalar: two v_readlane_b32
+__device__ __forceinline__ double sbm_lane_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+#define SBM_LANE_BCAST(v, src) sbm_lane_bcast(v, src)
 
 __device__ __forceinline__ double sbm_bcast0(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -98,6 +105,24 @@ constexpr double E1 = 71.0 / 57600.0, E3 = -71.0 / 16695.0, E4 = 71.0 / 1920.0, 
 #define SBM_ALL(c, i)                       \
   _Pragma("unroll") for (int c = 0; c < CPL; ++c) \
   _Pragma("unroll") for (int i = 0; i < NVX; ++i)
+// the NV column rows / the NX extra elements separately: a stage first forms its extra elements
+// (the stage STATE in the row-lane kernel), hands them to Sys::begin() -- which starts the
+// evaluation of f / J_y / J_p -- and only then forms the column rows, so that the latency of that
+// evaluation is covered by independent arithmetic
+#define SBM_MAIN(c, i)                      \
+  _Pragma("unroll") for (int c = 0; c < CPL; ++c) \
+  _Pragma("unroll") for (int i = 0; i < NV; ++i)
+#define SBM_EXTRA(c, i)                     \
+  _Pragma("unroll") for (int c = 0; c < CPL; ++c) \
+  _Pragma("unroll") for (int i = NV; i < NVX; ++i)
+// stage = extras, begin, mains, finish
+#define SBM_STAGE(tt, expr, kout)           \
+  {                                         \
+    SBM_EXTRA(c, i) zt[c][i] = (expr);      \
+    auto tok_ = sys.begin((tt), zt);        \
+    SBM_MAIN(c, i) zt[c][i] = (expr);       \
+    sys.finish(tok_, (tt), zt, kout);       \
+  }
 
 // ---------------------------------------------------------------------------
 // "System" policies: what differs between the two mappings
@@ -148,6 +173,10 @@ struct SensSystem {
     return anybad > 0.f ? __builtin_nanf("") : sqrtf(mx * (1.0f / NV));
   }
   __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
+  __device__ __forceinline__ int begin(double, const double (&)[CPL][NV]) const { return 0; }
+  __device__ __forceinline__ void finish(int, double t, const double (&z)[CPL][NV], double (&dz)[CPL][NV]) const {
+    rhs(t, z, dz);
+  }
 };
 
 // one trajectory per lane; state only
@@ -166,6 +195,10 @@ struct StateSystem {
     return sqrtf(colsum[0] * (1.0f / NV));
   }
   __device__ __forceinline__ double sum(double v) const { return v; }
+  __device__ __forceinline__ int begin(double, const double (&)[1][NV]) const { return 0; }
+  __device__ __forceinline__ void finish(int, double t, const double (&z)[1][NV], double (&dz)[1][NV]) const {
+    rhs(t, z, dz);
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -193,6 +226,9 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
   const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000;
 
   double k1[CPL][NVX], k2[CPL][NVX], k3[CPL][NVX], k4[CPL][NVX], k5[CPL][NVX], k6[CPL][NVX], zt[CPL][NVX];
+  // defined values everywhere from the start: lanes / elements that carry no equation must hold
+  // zeros, never whatever the previous kernel left in the register file
+  SBM_ALL(c, i) { k1[c][i] = 0.0; k2[c][i] = 0.0; k3[c][i] = 0.0; k4[c][i] = 0.0; k5[c][i] = 0.0; k6[c][i] = 0.0; zt[c][i] = 0.0; }
   double t = o.t0;
   SbmTrajOut out{SBM_OK, 0, 0};
   if (n_t <= 0) return out;
@@ -242,34 +278,25 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       if (t + 1.01 * hs >= target) { hs = target - t; last = true; }
 
       const double ha21 = hs * A21;
-      SBM_ALL(c, i) zt[c][i] = fma(ha21, k1[c][i], z[c][i]);
-      sys.rhs(t + C2 * hs, zt, k2);
-
+      SBM_STAGE(t + C2 * hs, fma(ha21, k1[c][i], z[c][i]), k2)
       const double ha31 = hs * A31, ha32 = hs * A32;
-      SBM_ALL(c, i) zt[c][i] = fma(ha32, k2[c][i], fma(ha31, k1[c][i], z[c][i]));
-      sys.rhs(t + C3 * hs, zt, k3);
-
+      SBM_STAGE(t + C3 * hs, fma(ha32, k2[c][i], fma(ha31, k1[c][i], z[c][i])), k3)
       const double ha41 = hs * A41, ha42 = hs * A42, ha43 = hs * A43;
-      SBM_ALL(c, i) zt[c][i] = fma(ha43, k3[c][i], fma(ha42, k2[c][i], fma(ha41, k1[c][i], z[c][i])));
-      sys.rhs(t + C4 * hs, zt, k4);
-
+      SBM_STAGE(t + C4 * hs, fma(ha43, k3[c][i], fma(ha42, k2[c][i], fma(ha41, k1[c][i], z[c][i]))), k4)
       const double ha51 = hs * A51, ha52 = hs * A52, ha53 = hs * A53, ha54 = hs * A54;
-      SBM_ALL(c, i)
-      zt[c][i] = fma(ha54, k4[c][i], fma(ha53, k3[c][i], fma(ha52, k2[c][i], fma(ha51, k1[c][i], z[c][i]))));
-      sys.rhs(t + C5 * hs, zt, k5);
-
+      SBM_STAGE(t + C5 * hs,
+                fma(ha54, k4[c][i], fma(ha53, k3[c][i], fma(ha52, k2[c][i], fma(ha51, k1[c][i], z[c][i])))), k5)
       const double ha61 = hs * A61, ha62 = hs * A62, ha63 = hs * A63, ha64 = hs * A64, ha65 = hs * A65;
-      SBM_ALL(c, i)
-      zt[c][i] = fma(ha65, k5[c][i],
-                     fma(ha64, k4[c][i], fma(ha63, k3[c][i], fma(ha62, k2[c][i], fma(ha61, k1[c][i], z[c][i])))));
-      sys.rhs(t + hs, zt, k6);
-
+      SBM_STAGE(t + hs,
+                fma(ha65, k5[c][i],
+                    fma(ha64, k4[c][i], fma(ha63, k3[c][i], fma(ha62, k2[c][i], fma(ha61, k1[c][i], z[c][i]))))),
+                k6)
       // 5th-order solution into zt; k2 is dead from here on and receives k7 = f(z_new) (FSAL)
       const double ha71 = hs * A71, ha73 = hs * A73, ha74 = hs * A74, ha75 = hs * A75, ha76 = hs * A76;
-      SBM_ALL(c, i)
-      zt[c][i] = fma(ha76, k6[c][i],
-                     fma(ha75, k5[c][i], fma(ha74, k4[c][i], fma(ha73, k3[c][i], fma(ha71, k1[c][i], z[c][i])))));
-      sys.rhs(t + hs, zt, k2);
+      SBM_STAGE(t + hs,
+                fma(ha76, k6[c][i],
+                    fma(ha75, k5[c][i], fma(ha74, k4[c][i], fma(ha73, k3[c][i], fma(ha71, k1[c][i], z[c][i]))))),
+                k2)
 
       // embedded error estimate; ratios and norm in f32 (they only steer the controller)
       const double he1 = hs * E1, he3 = hs * E3, he4 = hs * E4, he5 = hs * E5, he6 = hs * E6, he7 = hs * E7;
@@ -337,9 +364,11 @@ template <class Sys, class Store>
 __device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::CPL][Sys::NVX],
                                                const double* __restrict__ t_out, int n_t,
                                                const sbm_integrator_opts& o, Store&& store) {
+  constexpr int NV = Sys::NV;
   constexpr int NVX = Sys::NVX;
   constexpr int CPL = Sys::CPL;
   double k[CPL][NVX], acc[CPL][NVX], zt[CPL][NVX];
+  SBM_ALL(c, i) { k[c][i] = 0.0; acc[c][i] = 0.0; zt[c][i] = 0.0; }
   SbmTrajOut out{SBM_OK, 0, 0};
   const double h0 = o.h0;
   const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000000;
@@ -359,12 +388,12 @@ __device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::C
         for (int s = 0; s < ns; ++s) {
           const double ts = fma((double)s, hs, t0);
           sys.rhs(ts, z, k);
-          SBM_ALL(c, i) { acc[c][i] = k[c][i]; zt[c][i] = fma(hh, k[c][i], z[c][i]); }
-          sys.rhs(ts + hh, zt, k);
-          SBM_ALL(c, i) { acc[c][i] = fma(2.0, k[c][i], acc[c][i]); zt[c][i] = fma(hh, k[c][i], z[c][i]); }
-          sys.rhs(ts + hh, zt, k);
-          SBM_ALL(c, i) { acc[c][i] = fma(2.0, k[c][i], acc[c][i]); zt[c][i] = fma(hs, k[c][i], z[c][i]); }
-          sys.rhs(ts + hs, zt, k);
+          SBM_ALL(c, i) acc[c][i] = k[c][i];
+          SBM_STAGE(ts + hh, fma(hh, k[c][i], z[c][i]), k)
+          SBM_ALL(c, i) acc[c][i] = fma(2.0, k[c][i], acc[c][i]);
+          SBM_STAGE(ts + hh, fma(hh, k[c][i], z[c][i]), k)
+          SBM_ALL(c, i) acc[c][i] = fma(2.0, k[c][i], acc[c][i]);
+          SBM_STAGE(ts + hs, fma(hs, k[c][i], z[c][i]), k)
           SBM_ALL(c, i) z[c][i] = fma(h6, acc[c][i] + k[c][i], z[c][i]);
         }
         out.n_acc += ns;
@@ -533,39 +562,79 @@ struct RowLaneSystem {
   int cls;                       // class of this lane's row, -1 on lanes without a row
   int yidx[M::RL_MAXYS];         // which state feeds operand slot s
   double ps[M::RL_MAXPS];        // this row's parameters
-  int jyout[M::RL_MAXJY];        // where this row's J_y entries go
+  int jyout[M::RL_MAXJY];        // where this row's J_y entries go (LDS-list variant)
   int apos[M::RL_MAXJP];         // where this row's J_p entries go in A
 
-  __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
+  // LDS traffic of ONE wave is processed in issue order, so a ds_read issued after a ds_write of
+  // another lane sees that write: no barrier and no waitcnt is needed between the phases below,
+  // only a compiler-level fence that keeps the memory operations in program order.
+#ifdef SBM_RL_BARRIER
+  __device__ __forceinline__ static void lds_order() { __syncthreads(); }
+#else
+  __device__ __forceinline__ static void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
+#endif
+
+  struct Token {
+    double f;                  // derivative of this lane's state component
+    double jy[M::RL_MAXJY];    // J_y entries of this lane's row (read by the other lanes via v_readlane)
+    double acol[NV];           // A[:, lane] = J_p column of this lane's sensitivity parameter
+  };
+  // phase 1: publish this lane's stage state, evaluate the lane's row, publish its J_p entries and
+  // fetch this lane's column of A.  Called BEFORE the column rows of the stage are formed so that
+  // the LDS round trips and the dependent arithmetic of the row are covered by that work.
+  __device__ __forceinline__ Token begin(double t, const double (&z)[1][NVX]) const {
+    Token k;
     sh->Y[lane] = z[0][NV];
-    __syncthreads();  // one wave per workgroup: this orders the LDS traffic, it is not a cross-wave barrier
+    lds_order();
     double ys[M::RL_MAXYS];
 #pragma unroll
     for (int s = 0; s < M::RL_MAXYS; ++s) ys[s] = sh->Y[yidx[s]];
-    double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+    double jp[M::RL_MAXJP];
+    k.f = 0.0;
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+    for (int s = 0; s < M::RL_MAXJY; ++s) k.jy[s] = 0.0;
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
-    M::class_dispatch(cls, t, ys, ps, f, jy, jp);
-#pragma unroll
-    for (int s = 0; s < M::RL_MAXJY; ++s) sh->JY[jyout[s]] = jy[s];
+    M::class_dispatch(cls, t, ys, ps, k.f, k.jy, jp);
+    lds_order();
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
-    __syncthreads();
+#ifdef SBM_RL_JY_LDS
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) sh->JY[jyout[s]] = k.jy[s];
+#endif
+    lds_order();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) k.acol[i] = sh->A[i * 64 + lane];
+    lds_order();
+    return k;
+  }
+  // phase 2: the lane's column, dz = J_y z + A[:, lane]
+  __device__ __forceinline__ void finish(const Token& k, double /*t*/, const double (&z)[1][NVX],
+                                         double (&dz)[1][NVX]) const {
     double zc[NV], dc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) zc[i] = z[0][i];
-    M::apply_rowlane(sh->JY, &sh->A[lane], zc, dc);
+#ifdef SBM_RL_JY_LDS
+    M::apply_rowlane_lds(sh->JY, k.acol, zc, dc);
+    lds_order();
+#else
+    M::apply_rowlane(k.jy, k.acol, zc, dc);
+#endif
 #pragma unroll
     for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
-    dz[0][NV] = f;
-    __syncthreads();  // the next stage overwrites Y / JY / A: keep this stage's reads ahead of it
+    dz[0][NV] = k.f;
+  }
+  __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
+    const Token k = begin(t, z);
+    finish(k, t, z, dz);
   }
   // max( RMS of the state error, max over columns of the column RMS ): the same test as the
   // per-wave kernel, with the state spread over the lanes
   __device__ __forceinline__ float norm(const float (&colsum)[1], float xsum) const {
-    const float m = colsum[0];
+    // lanes without a column / without a row carry no equation: they must not steer the controller
+    const float m = (lane < M::NK) ? colsum[0] : 0.f;
+    xsum = (lane < NV) ? xsum : 0.f;
     const float bad = (m != m || xsum != xsum) ? 1.f : 0.f;
     const float mx = sbm_wave_max((m != m) ? 0.f : m);
     float xs = (xsum != xsum) ? 0.f : xsum;

@@ -114,26 +114,48 @@ def emit_rowlane_members(spec, d, meta, make_printer):
     for s in range(meta['max_ps']):
         smap['PS_%d' % s] = 'ps[%d]' % s
     pr = make_printer(smap)
+    # Branch-free: every class body is evaluated on every lane (a divergent if/else chain would
+    # execute all bodies one after the other anyway) and the lane keeps the results of ITS class
+    # through by-value selects.  No per-lane control flow is left in the kernel, which matters
+    # because other lanes read these registers with v_readlane.
     for ci, c in enumerate(classes):
-        L.append("    %sif (cls == %d) {  // rows %s" % ("" if ci == 0 else "else ", ci,
-                                                        ", ".join(str(r) for r in c['rows'])))
-        repl, red = cse(list(c['canon']), symbols=sympy.numbered_symbols('x_'), optimizations='basic')
-        for s, e in repl:
-            L.append("      const double %s = %s;" % (s, pr.doprint(e)))
-        L.append("      f = %s;" % pr.doprint(red[0]))
+        L.append("    // class %d: rows %s" % (ci, ", ".join(str(r) for r in c['rows'])))
+        repl, red = cse(list(c['canon']), symbols=sympy.numbered_symbols('c%d_x' % ci), optimizations='basic')
+        for sym, e in repl:
+            L.append("    const double %s = %s;" % (sym, pr.doprint(e)))
+        L.append("    const bool is%d = (cls == %d);" % (ci, ci))
+        L.append("    f = SBM_SEL(is%d, %s, f);" % (ci, pr.doprint(red[0])))
         for k in range(c['n_jy']):
-            L.append("      jy[%d] = %s;" % (k, pr.doprint(red[1 + k])))
+            L.append("    jy[%d] = SBM_SEL(is%d, %s, jy[%d]);" % (k, ci, pr.doprint(red[1 + k]), k))
         for k in range(c['n_jp']):
-            L.append("      jp[%d] = %s;" % (k, pr.doprint(red[1 + c['n_jy'] + k])))
-        L.append("    }")
+            L.append("    jp[%d] = SBM_SEL(is%d, %s, jp[%d]);" % (k, ci, pr.doprint(red[1 + c['n_jy'] + k]), k))
+    # which (row lane, slot) holds J_y non-zero e
+    where = {}
+    for i in range(n):
+        for k, (e_idx, c) in enumerate(d.jy_rows[i]):
+            where[e_idx] = (i, k)
     L += ["  }", "",
-          "  // dz = J_y z + A[:, lane]; jysh wave-uniform list of the J_y non-zeros, acol = &A[0][lane]",
+          "  // dz = J_y z + acol, one sensitivity column per lane.  J_y[i,m] sits in register jy[slot] of",
+          "  // row lane i: SBM_LANE_BCAST (v_readlane, literal lane) turns it into a scalar operand;",
+          "  // acol[i] = A[i][lane] was fetched from LDS ahead of time.",
           "  template <int NZ>",
-          "  __device__ __forceinline__ static void apply_rowlane(const double* jysh, const double* acol,",
+          "  __device__ __forceinline__ static void apply_rowlane(const double (&jy)[RL_MAXJY], const double (&acol)[NV],",
           "                                                       const double (&z)[NZ], double (&dz)[NZ]) {",
+          "    (void)jy;"]
+    for i in range(n):
+        expr = "acol[%d]" % i
+        for e_idx, c in d.jy_rows[i]:
+            r, k = where[e_idx]
+            expr = "fma(SBM_LANE_BCAST(jy[%d], %d), z[%d], %s)" % (k, r, c, expr)
+        L.append("    dz[%d] = %s;" % (i, expr))
+    L += ["  }",
+          "  // same with the J_y non-zeros read from an LDS list (jysh[e], wave-uniform addresses)",
+          "  template <int NZ>",
+          "  __device__ __forceinline__ static void apply_rowlane_lds(const double* jysh, const double (&acol)[NV],",
+          "                                                           const double (&z)[NZ], double (&dz)[NZ]) {",
           "    (void)jysh;"]
     for i in range(n):
-        expr = "acol[%d * 64]" % i
+        expr = "acol[%d]" % i
         for e_idx, c in d.jy_rows[i]:
             expr = "fma(jysh[%d], z[%d], %s)" % (e_idx, c, expr)
         L.append("    dz[%d] = %s;" % (i, expr))

@@ -61,3 +61,17 @@ def gpu_models(zoo):
             cache[name] = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=name)
         return cache[name]
     return get
+
+
+@pytest.fixture(autouse=True)
+def poison_register_file(request):
+    """Before every GPU test, run a kernel that leaves NaNs in the register file of every CU: a value
+    read before it is written then shows up as NaN instead of as the plausible-looking leftovers of
+    the previous launch (this is how an uninitialised read in the row-lane kernel was caught)."""
+    if request.node.get_closest_marker('gpu') is not None and has_gpu():
+        import torch
+        x = torch.full((64 * 1024 * 1024,), float('nan'), dtype=torch.float64, device='cuda')
+        y = x * 2.0 + x
+        torch.cuda.synchronize()
+        del x, y
+    yield

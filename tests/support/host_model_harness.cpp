@@ -1,6 +1,9 @@
 // Host harness for a generated model header: compiles SbmModel with g++ (device
 // qualifiers stubbed out) and exposes the augmented RHS exactly as the sensitivity
-// kernel assembles it (eval_jac once, apply_col per column, state in column 0).
+// kernels assemble it, in each of the emitted forms:
+//   h_sens_rhs          eval_jac once, apply_col per column, state in column 0   (per-wave kernel, CPL > 1)
+//   h_sens_rhs_fused    eval_col per column                                      (per-wave kernel, CPL == 1)
+//   h_sens_rhs_rowlane  class_dispatch per row lane + apply_rowlane per column   (row-lane kernel)
 // Used by tests/test_symbolic.py to pin the HIP text to the Python/C emitters on CPU.
 #include <cmath>
 #define __device__
@@ -9,6 +12,13 @@
 #define SBM_RCP(x) (1.0 / (x))
 #define SBM_PICK(scol, c, v, otherwise) ((scol) == (c) ? (v) : (otherwise))
 #define SBM_SEL(c, a, b) ((c) ? (a) : (b))
+// On the device SBM_LANE_BCAST(jy[slot], lane) reads register jy[slot] of another lane.  Here the
+// "lane registers" are the table g_lane_jy[lane][slot]; `v` names jy[slot] of an array whose base
+// address is g_bcast_base, which recovers the slot.
+static const double* g_bcast_base = nullptr;
+static double g_lane_jy[64][8];
+static inline double h_lane_bcast(const double* which, int src) { return g_lane_jy[src][which - g_bcast_base]; }
+#define SBM_LANE_BCAST(v, src) h_lane_bcast(&(v), (src))
 using std::fma;
 #include SBM_MODEL_HEADER
 
@@ -16,6 +26,7 @@ extern "C" {
 int h_n_vars() { return SbmModel::NV; }
 int h_n_params() { return SbmModel::NP; }
 int h_n_sens() { return SbmModel::NK; }
+int h_n_classes() { return SbmModel::RL_NCLASS; }
 
 void h_rhs(const double* y, double t, double* yout, const double* p) {
   double yy[SbmModel::NV], f[SbmModel::NV];
@@ -39,7 +50,6 @@ void h_sens_rhs(const double* y, double t, double* yout, const double* p) {
   }
 }
 
-// the same through the fused per-row form the DOPRI/RK4 kernels call (eval_col)
 void h_sens_rhs_fused(const double* y, double t, double* yout, const double* p) {
   constexpr int N = SbmModel::NV, K = SbmModel::NK;
   double yy[N], z[N], dz[N];
@@ -53,12 +63,11 @@ void h_sens_rhs_fused(const double* y, double t, double* yout, const double* p) 
   }
 }
 
-// the row-lane form: every row lane evaluates its class body on its own operands and drops the
-// results into the J_y list / additive matrix; every column then runs apply_rowlane
 void h_sens_rhs_rowlane(const double* y, double t, double* yout, const double* p) {
   constexpr int N = SbmModel::NV, K = SbmModel::NK;
+  static_assert(SbmModel::RL_MAXJY <= 8, "harness table too small");
   static double ash[N * 64 + 2];
-  double jysh[SbmModel::NJY + 2], z[N], dz[N];
+  double z[N], dz[N], acol[N];
   for (int i = 0; i < N * 64 + 2; ++i) ash[i] = 0.0;
   for (int row = 0; row < N; ++row) {
     double ys[SbmModel::RL_MAXYS], ps[SbmModel::RL_MAXPS], f = 0.0, jy[SbmModel::RL_MAXJY], jp[SbmModel::RL_MAXJP];
@@ -67,13 +76,15 @@ void h_sens_rhs_rowlane(const double* y, double t, double* yout, const double* p
     for (int s = 0; s < SbmModel::RL_MAXJY; ++s) jy[s] = 0.0;
     for (int s = 0; s < SbmModel::RL_MAXJP; ++s) jp[s] = 0.0;
     SbmModel::class_dispatch(SbmModel::rl_class(row), t, ys, ps, f, jy, jp);
-    for (int s = 0; s < SbmModel::RL_MAXJY; ++s) jysh[SbmModel::rl_jyout(s, row)] = jy[s];
+    for (int s = 0; s < SbmModel::RL_MAXJY; ++s) g_lane_jy[row][s] = jy[s];
     for (int s = 0; s < SbmModel::RL_MAXJP; ++s) ash[SbmModel::rl_apos(s, row)] = jp[s];
     yout[row] = f;
   }
+  double jy_names[SbmModel::RL_MAXJY] = {0};  // only its addresses matter (slot recovery)
+  g_bcast_base = jy_names;
   for (int c = 0; c < K; ++c) {
-    for (int i = 0; i < N; ++i) z[i] = y[N + i * K + c];
-    SbmModel::apply_rowlane(jysh, ash + c, z, dz);
+    for (int i = 0; i < N; ++i) { z[i] = y[N + i * K + c]; acol[i] = ash[i * 64 + c]; }
+    SbmModel::apply_rowlane(jy_names, acol, z, dz);
     for (int i = 0; i < N; ++i) yout[N + i * K + c] = dz[i];
   }
 }
