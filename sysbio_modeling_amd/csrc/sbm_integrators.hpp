@@ -564,6 +564,7 @@ struct RowLaneSystem {
   double ps[M::RL_MAXPS];        // this row's parameters
   int jyout[M::RL_MAXJY];        // where this row's J_y entries go (LDS-list variant)
   int apos[M::RL_MAXJP];         // where this row's J_p entries go in A
+  double sj[M::RL_NSTATIC > 0 ? M::RL_NSTATIC : 1];  // parameter-only J_y entries, wave-uniform
 
   // LDS traffic of ONE wave is processed in issue order, so a ds_read issued after a ds_write of
   // another lane sees that write: no barrier and no waitcnt is needed between the phases below,
@@ -577,7 +578,6 @@ struct RowLaneSystem {
   struct Token {
     double f;                  // derivative of this lane's state component
     double jy[M::RL_MAXJY];    // J_y entries of this lane's row (read by the other lanes via v_readlane)
-    double acol[NV];           // A[:, lane] = J_p column of this lane's sensitivity parameter
   };
   // phase 1: publish this lane's stage state, evaluate the lane's row, publish its J_p entries and
   // fetch this lane's column of A.  Called BEFORE the column rows of the stage are formed so that
@@ -604,9 +604,6 @@ struct RowLaneSystem {
     for (int s = 0; s < M::RL_MAXJY; ++s) sh->JY[jyout[s]] = k.jy[s];
 #endif
     lds_order();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) k.acol[i] = sh->A[i * 64 + lane];
-    lds_order();
     return k;
   }
   // phase 2: the lane's column, dz = J_y z + A[:, lane]
@@ -615,11 +612,17 @@ struct RowLaneSystem {
     double zc[NV], dc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) zc[i] = z[0][i];
+    // A[:, lane] is fetched here rather than in begin(): holding 2*NV more registers across the
+    // column rows costs more (AGPR traffic) than the exposed LDS latency (measured 12.8 vs 13.3 ms)
+    double acol[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acol[i] = sh->A[i * 64 + lane];
+    lds_order();
 #ifdef SBM_RL_JY_LDS
-    M::apply_rowlane_lds(sh->JY, k.acol, zc, dc);
+    M::apply_rowlane_lds(sh->JY, acol, zc, dc);
     lds_order();
 #else
-    M::apply_rowlane(k.jy, k.acol, zc, dc);
+    M::apply_rowlane(k.jy, sj, acol, zc, dc);
 #endif
 #pragma unroll
     for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
@@ -679,6 +682,17 @@ __global__ void __launch_bounds__(64) sbm_sens_rowlane_kernel(sbm_kernel_args a)
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJP; ++s) sys.apos[s] = has_row ? M::rl_apos(s, row) : NV * 64 + 1;
   __syncthreads();
+  {  // parameter-only J_y entries: evaluate the rows once (any state will do) and broadcast them
+    double ys0[M::RL_MAXYS], f0 = 0.0, jy0[M::RL_MAXJY], jp0[M::RL_MAXJP];
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXYS; ++s) ys0[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) jy0[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) jp0[s] = 0.0;
+    M::class_dispatch(sys.cls, a.opts.t0, ys0, sys.ps, f0, jy0, jp0);
+    M::rl_static(jy0, sys.sj);
+  }
 
   const int goff = a.grid_off ? a.grid_off[traj] : 0;
   const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;

@@ -129,24 +129,46 @@ def emit_rowlane_members(spec, d, meta, make_printer):
             L.append("    jy[%d] = SBM_SEL(is%d, %s, jy[%d]);" % (k, ci, pr.doprint(red[1 + k]), k))
         for k in range(c['n_jp']):
             L.append("    jp[%d] = SBM_SEL(is%d, %s, jp[%d]);" % (k, ci, pr.doprint(red[1 + c['n_jy'] + k]), k))
-    # which (row lane, slot) holds J_y non-zero e
+    # which (row lane, slot) holds J_y non-zero e; entries that depend on parameters only are
+    # STATIC: the same for every stage of every step, broadcast once per kernel (rl_static)
     where = {}
     for i in range(n):
         for k, (e_idx, c) in enumerate(d.jy_rows[i]):
             where[e_idx] = (i, k)
+    var_names = set(spec.variables)
+    static_idx = {}
+    for e_idx in sorted(where):
+        syms = {str(x) for x in d.jy_c[e_idx].free_symbols}
+        if not (syms & var_names) and 't' not in syms:
+            static_idx[e_idx] = len(static_idx)
+    nst = max(len(static_idx), 1)
     L += ["  }", "",
-          "  // dz = J_y z + acol, one sensitivity column per lane.  J_y[i,m] sits in register jy[slot] of",
-          "  // row lane i: SBM_LANE_BCAST (v_readlane, literal lane) turns it into a scalar operand;",
-          "  // acol[i] = A[i][lane] was fetched from LDS ahead of time.",
-          "  template <int NZ>",
-          "  __device__ __forceinline__ static void apply_rowlane(const double (&jy)[RL_MAXJY], const double (&acol)[NV],",
-          "                                                       const double (&z)[NZ], double (&dz)[NZ]) {",
+          "  static constexpr int RL_NSTATIC = %d;   // J_y entries that depend on parameters only" % len(static_idx),
+          "  // run once per kernel, after one class_dispatch: broadcast the static entries",
+          "  __device__ __forceinline__ static void rl_static(const double (&jy)[RL_MAXJY], double (&sj)[%d]) {" % nst,
           "    (void)jy;"]
+    if not static_idx:
+        L.append("    sj[0] = 0.0;")
+    for e_idx, si in static_idx.items():
+        r, k = where[e_idx]
+        L.append("    sj[%d] = SBM_LANE_BCAST(jy[%d], %d);" % (si, k, r))
+    L += ["  }", "",
+          "  // dz = J_y z + acol, one sensitivity column per lane.  A state-dependent J_y[i,m] sits in",
+          "  // register jy[slot] of row lane i: SBM_LANE_BCAST (v_readlane, literal lane) turns it into a",
+          "  // scalar operand; static entries come from sj; acol[i] = A[i][lane] was fetched from LDS.",
+          "  template <int NZ>",
+          "  __device__ __forceinline__ static void apply_rowlane(const double (&jy)[RL_MAXJY], const double (&sj)[%d]," % nst,
+          "                                                       const double (&acol)[NV], const double (&z)[NZ],",
+          "                                                       double (&dz)[NZ]) {",
+          "    (void)jy; (void)sj;"]
     for i in range(n):
         expr = "acol[%d]" % i
         for e_idx, c in d.jy_rows[i]:
-            r, k = where[e_idx]
-            expr = "fma(SBM_LANE_BCAST(jy[%d], %d), z[%d], %s)" % (k, r, c, expr)
+            if e_idx in static_idx:
+                expr = "fma(sj[%d], z[%d], %s)" % (static_idx[e_idx], c, expr)
+            else:
+                r, k = where[e_idx]
+                expr = "fma(SBM_LANE_BCAST(jy[%d], %d), z[%d], %s)" % (k, r, c, expr)
         L.append("    dz[%d] = %s;" % (i, expr))
     L += ["  }",
           "  // same with the J_y non-zeros read from an LDS list (jysh[e], wave-uniform addresses)",

@@ -82,9 +82,12 @@ void h_sens_rhs_rowlane(const double* y, double t, double* yout, const double* p
   }
   double jy_names[SbmModel::RL_MAXJY] = {0};  // only its addresses matter (slot recovery)
   g_bcast_base = jy_names;
+  // parameter-only J_y entries are broadcast once per kernel (here: from the same lane table)
+  double sj[SbmModel::RL_NSTATIC > 0 ? SbmModel::RL_NSTATIC : 1];
+  SbmModel::rl_static(jy_names, sj);
   for (int c = 0; c < K; ++c) {
     for (int i = 0; i < N; ++i) { z[i] = y[N + i * K + c]; acol[i] = ash[i * 64 + c]; }
-    SbmModel::apply_rowlane(jy_names, acol, z, dz);
+    SbmModel::apply_rowlane(jy_names, sj, acol, z, dz);
     for (int i = 0; i < N; ++i) yout[N + i * K + c] = dz[i];
   }
 }
