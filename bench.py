@@ -196,11 +196,12 @@ def main():
             traffic = json.load(fh).get(args.method, {}).get('hbm_bytes_per_launch')
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "sbm_sens_kernel<cascade20,%s>" % args.method, "kernel_ms": k_ms,
+                "kernel": "sbm_sens_rowlane_kernel<cascade20,%s>" % args.method, "kernel_ms": k_ms,
                 "steps_per_launch": k_steps, "algorithmic_bytes_per_step": BYTES_PER_STEP,
                 "kernel_steps_per_s": k_steps / (k_ms * 1e-3),
                 "note": "algorithmic bytes (2*8*820 B per accepted step) / kernel time; the kernel keeps the "
-                        "state in VGPRs, so real HBM traffic ('traffic') is far below this figure"}
+                        "state in VGPRs, so real HBM traffic ('traffic', PMC) is far below this figure and the "
+                        "binding resource is VALU issue (profiles/r01b/pmc_summary.json)"}
 
     extras = {}
     if not args.no_extras and rank == 0:
