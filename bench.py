@@ -230,6 +230,26 @@ def main():
                   "sens_rk4_fixed_%d_per_wave_variant" % args.rk4_steps: time_kernel('sens', rk_pw),
                   "state_only_dopri45_configs1": time_kernel('state', dp),
                   "state_only_rk4_fixed_%d" % args.rk4_steps: time_kernel('state', rk)}
+        # BASELINE configs[3]: 8 experiment settings x 1024 vectors, residual + Jacobian assembly
+        import warnings
+        from sysbio_modeling_amd import models_zoo
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            p4, th4 = models_zoo.cascade_config4_project(model)
+        t4 = torch.from_numpy(models_zoo.config4_ensemble(th4, 1024)).to(dev)
+        p4.evaluate_batch(t4, jacobian=True, want=('jacobian',))
+        torch.cuda.synchronize(dev)
+        a4, b4 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a4.record()
+        for _ in range(3):
+            o4 = p4.evaluate_batch(t4, jacobian=True, want=('jacobian',))
+        b4.record()
+        torch.cuda.synchronize(dev)
+        ms4 = a4.elapsed_time(b4) / 3
+        st4 = int(o4['n_steps'].sum().item())
+        extras["configs3_project_8exp_x_1024vec"] = {"ms": ms4, "steps": st4, "steps_per_s": st4 / (ms4 * 1e-3),
+                                                     "rows": 512, "params": 68,
+                                                     "failed_vectors": int((o4['status'] != 0).sum().item())}
 
     result = {
         "metric": "ensemble ODE-steps/sec (20-state model + fwd sens)",

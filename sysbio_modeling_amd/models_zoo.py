@@ -135,3 +135,60 @@ def stiff_nominal_params(n=50):
     a = 10.0 ** np.linspace(-2.0, 4.0, n)
     b = 0.5 * np.ones(n)
     return np.concatenate([a, b])
+
+
+# ----------------------------------------------------------------------------
+# BASELINE.json configs[3]: multi-experiment Project on the cascade model
+# ----------------------------------------------------------------------------
+def cascade_config4_project(model, n_exp=8, seed=7, simulate=None, project_cls=None, **project_kw):
+    """E experiments 'exp_0'..; setting cond = e; d0..d3 each in its own 'Shared' group keyed on cond
+    (4 x E slots), the other 36 parameters Global => q = 36 + 4 E (68 at E = 8).  Each experiment:
+    species 4/9/14/19 'direct', 16 timepoints linspace(6.25, 100, 16), sigma = 0.05 |data| + 0.01,
+    data = model at nominal parameters (d0..d3 scaled by 1 + 0.1 cond) x (1 + 5 % noise), one scale
+    factor per measured species => R = 64 E (512), q = 68, as SURVEY.md section 8(d) specifies.
+
+    ``simulate(p, t_out) -> (len(t_out), n)``: where the synthetic data come from (default: the
+    model's own GPU simulate; the oracle-side tests pass the SciPy restatement instead).
+    Returns (project, theta_nominal)."""
+    from .experiment import Experiment
+    from .measurement import TimecourseMeasurement
+    if project_cls is None:
+        from .project import Project as project_cls
+    names = list(model.param_order)
+    p_nom = cascade_nominal_params()
+    grid = np.linspace(0, CASCADE_T_END, 1000)
+    idx = np.searchsorted(grid, CASCADE_MEASURE_TIMES)
+    t_out = np.concatenate([[0.0], grid[idx]])
+    if simulate is None:
+        def simulate(p, t):
+            return model.simulate(p, t)
+    rng = np.random.default_rng(seed)
+    exps = []
+    for c in range(n_exp):
+        p = p_nom.copy()
+        p[20:24] *= 1.0 + 0.1 * c
+        y = simulate(p, t_out)[1:]
+        ms = []
+        for v in CASCADE_MEASURED_SPECIES:
+            data = y[:, v] * (1.0 + 0.05 * rng.standard_normal(len(idx)))
+            ms.append(TimecourseMeasurement('s%d' % v, data, CASCADE_MEASURE_TIMES.copy(), 0.05 * np.abs(data) + 0.01))
+        exps.append(Experiment('exp_%d' % c, ms, experiment_settings={'cond': c}))
+    shared = OrderedDict(('deg%d' % i, {('d%d' % i): ('cond',)}) for i in range(4))
+    settings = {'Global': [n for n in names if n not in ('d0', 'd1', 'd2', 'd3')], 'Shared': shared}
+    mapping = {('s%d' % v): ('direct', v) for v in CASCADE_MEASURED_SPECIES}
+    proj = project_cls(model, exps, settings, mapping, sf_groups=['s%d' % v for v in CASCADE_MEASURED_SPECIES],
+                       **project_kw)
+    theta = np.zeros(proj.n_project_params)
+    idx_map = proj.project_param_idx
+    for g, slots in idx_map.items():
+        for key, gi in slots.items():
+            if g.startswith('deg'):
+                theta[gi] = np.log(p_nom[20 + int(g[3:])] * (1.0 + 0.1 * key[0]))
+            else:
+                theta[gi] = np.log(p_nom[names.index(g)])
+    return proj, theta
+
+
+def config4_ensemble(theta_nominal, n_vectors=1024, seed=20261003, spread=0.5):
+    rng = np.random.default_rng(seed)
+    return theta_nominal[None, :] + spread * rng.standard_normal((n_vectors, theta_nominal.size))
