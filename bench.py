@@ -275,6 +275,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()   # rank 0 arrives late (extras run after the timed region)
         dist.destroy_process_group()
 
 

@@ -176,7 +176,16 @@ typedef struct sbm_project_desc {
    * and prior rows of J stay zero (base_project.py:519-530 is never called).
    * 0 gives d r / d theta (J/sigma, prior rows 1/sigma_prior). */
   int32_t reference_compat;
+  /* SBM_LOSS_SQUARE:      r = (B s - d)/sigma                (squared_loss_function.py:27-42)
+   * SBM_LOSS_LOG_SQUARE:  r = (log(B s) - log d)/sigma, geometric-mean scale factor with weights
+   *                       (d/sigma)^2, J = J_m/s + (dB/dtheta)/B
+   *                       (log_squared_loss_function.py:23-98, log_scale_factor.py:17-36); needs d > 0.
+   * The reference's NormalizedSquareLossFunction (normalized_squared_loss_function.py:23-46) is
+   * SBM_LOSS_SQUARE with row_sigma already multiplied by row_data on the host. */
+  int32_t loss_type;
 } sbm_project_desc;
+
+enum { SBM_LOSS_SQUARE = 0, SBM_LOSS_LOG_SQUARE = 1 };
 
 int sbm_project_load(sbm_model* m, const sbm_project_desc* desc, sbm_project** out);
 int sbm_project_unload(sbm_project* p);

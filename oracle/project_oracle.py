@@ -50,7 +50,10 @@ N_GRID = 1000  # base_project.py:419,510
 
 class ProjectOracle(object):
     def __init__(self, gm, experiments, model_parameter_settings, measurement_to_model_map,
-                 sf_groups=None, reference_compat=True, use_c=True):
+                 sf_groups=None, reference_compat=True, use_c=True, loss='square'):
+        # 'square' | 'log' (log_squared_loss_function.py, log_scale_factor.py) |
+        # 'normalized' (normalized_squared_loss_function.py: sigma *= mean, then 'square')
+        self.loss = loss
         self.gm = gm
         self.param_order = list(gm.param_order)
         self.n_vars = gm.n_vars
@@ -136,6 +139,8 @@ class ProjectOracle(object):
             for m in exp.measurements:
                 vals, std, tps = m.get_nonzero_measurements()
                 for v, s_, t in zip(vals, std, tps):
+                    if getattr(self, 'loss', 'square') == 'normalized':
+                        s_ = s_ * v                      # normalized_squared_loss_function.py:40-46
                     out.append((ei, m.variable_name, float(v), float(s_), float(t)))
         return out
 
@@ -221,6 +226,17 @@ class ProjectOracle(object):
         for g in range(G):
             sel = grp == g
             s, dd, ss = sims[sel], d[sel], sg[sel]
+            if getattr(self, 'loss', 'square') == 'log':
+                es = ss / dd                                             # log_scale_factor.py:18
+                inv_std_sum = np.sum(1.0 / es ** 2)                      # :20
+                log_data = np.exp(np.sum(np.log(dd) / es ** 2) / inv_std_sum)    # :21
+                log_sim = np.exp(-np.sum(np.log(s) / es ** 2) / inv_std_sum)     # :24
+                B[g] = log_data * log_sim                                # :26
+                if J is not None:
+                    Jg = J[sel]
+                    exp_grad = (-1.0 / inv_std_sum) * np.sum(Jg.T / (s * es ** 2), axis=1)   # :33-35
+                    dB[g] = B[g] * exp_grad                              # :36
+                continue
             sim_dot_exp = np.sum((s * dd) / ss ** 2)
             sim_dot_sim = np.sum((s * s) / ss ** 2)
             B[g] = sim_dot_exp / sim_dot_sim
@@ -244,7 +260,12 @@ class ProjectOracle(object):
         B, _, grp, d, sg = self._sf(rows, sims)
         self.scale_factors = list(B)
         scaled = sims * np.where(grp >= 0, B[np.clip(grp, 0, None)], 1.0) if len(B) else sims
-        res = list((scaled - d) / sg)                                # :40
+        if getattr(self, 'loss', 'square') == 'log':
+            if np.min(d) <= 0:
+                raise ValueError("LogSquare loss cannot handle measurements smaller or equal to zero")
+            res = list((np.log(scaled) - np.log(d)) / sg)             # log_squared_loss_function.py:56-64
+        else:
+            res = list((scaled - d) / sg)                            # :40
         for val, mean, sigma, _ in pri:
             res.append((val - mean) / sigma)
         for gi, (mean, sigma) in self.sf_priors.items():             # linear_scale_factor.py:55-61
@@ -268,9 +289,15 @@ class ProjectOracle(object):
             return np.full((n_tot, q), np.inf)
         B, dB, grp, d, sg = self._sf(rows, sims, J)
         out = J.copy()
-        for g in range(len(self.sf_groups)):                         # :59-78: B*J + sim (x) dB/dtheta
-            sel = grp == g
-            out[sel] = J[sel] * B[g] + sims[sel][:, None] * dB[g][None, :]
+        if getattr(self, 'loss', 'square') == 'log':
+            out = J / sims[:, None]                                  # log_squared_loss_function.py:69,92
+            for g in range(len(self.sf_groups)):
+                sel = grp == g
+                out[sel] = out[sel] + (dB[g] / B[g])[None, :]         # :92-93
+        else:
+            for g in range(len(self.sf_groups)):                     # :59-78: B*J + sim (x) dB/dtheta
+                sel = grp == g
+                out[sel] = J[sel] * B[g] + sims[sel][:, None] * dB[g][None, :]
         if not self.compat:
             out = out / sg[:, None]
         extra = []

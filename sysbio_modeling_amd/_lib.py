@@ -38,7 +38,7 @@ class ProjectDesc(ctypes.Structure):
         ('row_data', c_double_p), ('row_sigma', c_double_p), ('row_sf', c_int32_p),
         ('prior_idx', c_int32_p), ('prior_mean', c_double_p), ('prior_sigma', c_double_p),
         ('sf_prior_group', c_int32_p), ('sf_prior_mean', c_double_p), ('sf_prior_sigma', c_double_p),
-        ('reference_compat', ctypes.c_int32),
+        ('reference_compat', ctypes.c_int32), ('loss_type', ctypes.c_int32),
     ]
 
 

@@ -80,7 +80,7 @@ struct DevBuf {
 
 struct sbm_project {
   sbm_model* model;
-  int E, q, R, G, NPR, NSP, compat;
+  int E, q, R, G, NPR, NSP, compat, loss;
   int n_params, n_vars, n_sens;
   int n_t_max;  // longest per-experiment grid
   // static device data
@@ -363,7 +363,7 @@ __device__ __forceinline__ double block_sum(double v, double* red /*[4]*/) {
 
 struct AssembleArgs {
   // static project data
-  int E, q, R, G, NPR, NSP, NP, NV, NK, n_t, compat;
+  int E, q, R, G, NPR, NSP, NP, NV, NK, n_t, compat, loss;
   const int32_t *row_exp, *row_tidx, *row_var_off, *row_vars, *row_sf, *prior_idx, *sfp_group;
   const double *row_data, *row_sigma, *prior_mean, *prior_sigma, *sfp_mean, *sfp_sigma;
   const int32_t *inv_ptr, *inv_m;  // [E][q+1] CSR: model params mapped to project column c in experiment e
@@ -423,7 +423,8 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
     double s = 0.0;
     for (int k = a.row_var_off[r]; k < a.row_var_off[r + 1]; ++k) s += a.Y[base + a.row_vars[k]];
     s_sim[r] = s;
-    if (!(s == s)) atomicMax(&s_bad, (int)SBM_NON_FINITE);
+    // NaN simulations -> inf rows; the log loss cannot take a non-positive simulation either
+    if (!(s == s) || (a.loss == SBM_LOSS_LOG_SQUARE && !(s > 0.0))) atomicMax(&s_bad, (int)SBM_NON_FINITE);
   }
   __syncthreads();
   const int bad = s_bad;
@@ -451,9 +452,16 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
     double sde = 0.0, sds = 0.0;
     for (int r = tid; r < R; r += blockDim.x) {
       if (a.row_sf[r] == g) {
-        const double w = 1.0 / (a.row_sigma[r] * a.row_sigma[r]);
-        sde += s_sim[r] * a.row_data[r] * w;
-        sds += s_sim[r] * s_sim[r] * w;
+        if (a.loss == SBM_LOSS_LOG_SQUARE) {
+          // log_scale_factor.py:17-28: weights 1/(sigma/d)^2; log B = sum(w (log d - log s)) / sum(w)
+          const double w = (a.row_data[r] * a.row_data[r]) / (a.row_sigma[r] * a.row_sigma[r]);
+          sde += (log(a.row_data[r]) - log(s_sim[r])) * w;
+          sds += w;
+        } else {
+          const double w = 1.0 / (a.row_sigma[r] * a.row_sigma[r]);
+          sde += s_sim[r] * a.row_data[r] * w;
+          sds += s_sim[r] * s_sim[r] * w;
+        }
       }
     }
     sde = block_sum(sde, s_red);
@@ -461,8 +469,9 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
     if (tid == 0) {
       s_sde[g] = sde;
       s_sds[g] = sds;
-      s_B[g] = sde / sds;
-      if (a.sf) a.sf[(size_t)v * G + g] = sde / sds;
+      const double B = (a.loss == SBM_LOSS_LOG_SQUARE) ? exp(sde / sds) : sde / sds;
+      s_B[g] = B;
+      if (a.sf) a.sf[(size_t)v * G + g] = B;
     }
   }
   __syncthreads();
@@ -474,7 +483,8 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
     if (r < R) {
       const int g = a.row_sf[r];
       const double B = g >= 0 ? s_B[g] : 1.0;
-      res = (B * s_sim[r] - a.row_data[r]) / a.row_sigma[r];
+      res = (a.loss == SBM_LOSS_LOG_SQUARE) ? (log(B * s_sim[r]) - log(a.row_data[r])) / a.row_sigma[r]
+                                            : (B * s_sim[r] - a.row_data[r]) / a.row_sigma[r];
       s_res[r] = res;
     } else if (r < R + a.NPR) {
       const int k = r - R;
@@ -535,9 +545,13 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
         gcur = g; jde = 0.0; jds = 0.0;
       }
       if (g >= 0) {
-        const double w = 1.0 / (a.row_sigma[r] * a.row_sigma[r]);
-        jde += jm * a.row_data[r] * w;
-        jds += jm * s_sim[r] * w;
+        if (a.loss == SBM_LOSS_LOG_SQUARE) {  // log_scale_factor.py:30-36: sum J / (s (sigma/d)^2)
+          jde += jm * (a.row_data[r] * a.row_data[r]) / (a.row_sigma[r] * a.row_sigma[r] * s_sim[r]);
+        } else {
+          const double w = 1.0 / (a.row_sigma[r] * a.row_sigma[r]);
+          jde += jm * a.row_data[r] * w;
+          jds += jm * s_sim[r] * w;
+        }
       }
     }
     if (gcur >= 0) {
@@ -555,7 +569,9 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
       jds += s_part[((size_t)(1 * Gn + g) * rpp + l) * q + c];
     }
     const double sds = s_sds[g], sde = s_sde[g];
-    const double db = jde / sds - 2.0 * sde * jds / (sds * sds);
+    // square: dB = jde/sds - 2 sde jds/sds^2 ; log: dB = B * (-1/W) sum J/(s sigma'^2)
+    const double db = (a.loss == SBM_LOSS_LOG_SQUARE) ? -s_B[g] * jde / sds
+                                                      : jde / sds - 2.0 * sde * jds / (sds * sds);
     s_dB[i] = db;
     if (a.sf_grad) a.sf_grad[(size_t)v * G * q + i] = db;
   }
@@ -569,7 +585,13 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
       if (r < R) {
         const int g = a.row_sf[r];
         val = Jv[i];
-        if (g >= 0) val = s_B[g] * val + s_sim[r] * s_dB[g * q + c];
+        if (a.loss == SBM_LOSS_LOG_SQUARE) {
+          // log_squared_loss_function.py:66-98: J/s (+ (dB/dtheta)/B for rows with a scale factor)
+          val = val / s_sim[r];
+          if (g >= 0) val += s_dB[g * q + c] / s_B[g];
+        } else if (g >= 0) {
+          val = s_B[g] * val + s_sim[r] * s_dB[g * q + c];
+        }
         if (!a.compat) val /= a.row_sigma[r];
       } else if (r < R + a.NPR) {
         const int k = r - R;
@@ -611,6 +633,8 @@ extern "C" int sbm_project_load(sbm_model* m, const sbm_project_desc* d, sbm_pro
   if (!m || !d || !out) return sbm_fail(SBM_E_ARG, "sbm_project_load: NULL argument");
   const int E = d->n_experiments, q = d->n_project_params, R = d->n_rows, G = d->n_sf_groups,
             NPR = d->n_prior_rows, NSP = d->n_sf_prior_rows, NP = m->info.n_params;
+  if (d->loss_type != SBM_LOSS_SQUARE && d->loss_type != SBM_LOSS_LOG_SQUARE)
+    return sbm_fail(SBM_E_ARG, "sbm_project_load: unknown loss_type %d", d->loss_type);
   if (E <= 0 || q <= 0 || R < 0 || G < 0 || NPR < 0 || NSP < 0)
     return sbm_fail(SBM_E_ARG, "sbm_project_load: bad sizes E=%d q=%d R=%d G=%d", E, q, R, G);
   if (!d->pmap || !d->pfixed || !d->sens_col || !d->tgrid_off || !d->tgrid || (R && (!d->row_exp || !d->row_tidx ||
@@ -643,6 +667,8 @@ extern "C" int sbm_project_load(sbm_model* m, const sbm_project_desc* d, sbm_pro
         return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d maps to variable %d of %d", r, d->row_vars[k], m->info.n_vars);
     if (d->row_sf[r] >= G) return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d sf group %d", r, d->row_sf[r]);
     if (d->row_sigma[r] == 0.0) return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d has sigma 0", r);
+    if (d->loss_type == SBM_LOSS_LOG_SQUARE && !(d->row_data[r] > 0.0))
+      return sbm_fail(SBM_E_ARG, "sbm_project_load: LogSquare loss cannot handle measurements smaller or equal to zero (row %d)", r);
   }
   for (int k = 0; k < NPR; ++k)
     if (d->prior_idx[k] < 0 || d->prior_idx[k] >= q) return sbm_fail(SBM_E_ARG, "sbm_project_load: prior index");
@@ -654,6 +680,7 @@ extern "C" int sbm_project_load(sbm_model* m, const sbm_project_desc* d, sbm_pro
   sbm_project* p = new sbm_project();
   p->model = m;
   p->E = E; p->q = q; p->R = R; p->G = G; p->NPR = NPR; p->NSP = NSP; p->compat = d->reference_compat;
+  p->loss = d->loss_type;
   p->n_params = NP; p->n_vars = m->info.n_vars; p->n_sens = m->info.n_sens; p->n_t_max = n_t_max;
 
   // inverse map: for experiment e and project column c, the model params that read it
@@ -767,6 +794,7 @@ static int project_run(sbm_project* p, const double* Theta, int V, const sbm_int
   memset(&g, 0, sizeof(g));
   g.E = p->E; g.q = p->q; g.R = p->R; g.G = p->G; g.NPR = p->NPR; g.NSP = p->NSP; g.NP = NP; g.NV = NV; g.NK = NK; g.n_t = nt;
   g.compat = p->compat;
+  g.loss = p->loss;
   g.row_exp = p->row_exp.p; g.row_tidx = p->row_tidx.p; g.row_var_off = p->row_var_off.p; g.row_vars = p->row_vars.p;
   g.row_sf = p->row_sf.p; g.prior_idx = p->prior_idx.p; g.row_data = p->row_data.p; g.row_sigma = p->row_sigma.p;
   g.prior_mean = p->prior_mean.p; g.prior_sigma = p->prior_sigma.p;

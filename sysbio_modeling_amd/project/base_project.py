@@ -305,10 +305,17 @@ class Project(object):
         p_idx, p_mean, p_sigma, _ = self._prior_rows()
         s_grp, s_mean, s_sigma, _ = self._sf_prior_rows()
         groups = self._loss_function.groups if hasattr(self._loss_function, 'groups') else []
-        return dict(E=E, q=self._n_project_params, R=len(rows['exp']), G=len(groups),
+        lf = self._loss_function
+        sigma = rows['sigma']
+        if getattr(lf, 'normalize_sigma_by_mean', False):
+            sigma = _as_f64(sigma * rows['data'])   # normalized_squared_loss_function.py:40-46
+        loss_type = int(getattr(lf, 'loss_type', 0))
+        if loss_type == 1 and len(rows['data']) and np.min(rows['data']) <= 0:
+            raise ValueError("LogSquare loss cannot handle measurements smaller or equal to zero")
+        return dict(E=E, q=self._n_project_params, R=len(rows['exp']), G=len(groups), loss_type=loss_type,
                     pmap=pmap, pfixed=pfixed, sens_col=sens_col, tgrid_off=tgrid_off, tgrid=_as_f64(tgrid),
                     row_exp=rows['exp'], row_tidx=rows['tidx'], row_var_off=_as_int32(var_off),
-                    row_vars=_as_int32(var_list), row_data=rows['data'], row_sigma=rows['sigma'],
+                    row_vars=_as_int32(var_list), row_data=rows['data'], row_sigma=sigma,
                     row_sf=rows['sf'], prior_idx=p_idx, prior_mean=p_mean, prior_sigma=p_sigma,
                     sf_prior_group=s_grp, sf_prior_mean=s_mean, sf_prior_sigma=s_sigma,
                     reference_compat=int(self.reference_compat))
@@ -334,7 +341,7 @@ class Project(object):
             dp(a['row_data']), dp(a['row_sigma']), ip(a['row_sf']),
             ip(a['prior_idx']), dp(a['prior_mean']), dp(a['prior_sigma']),
             ip(a['sf_prior_group']), dp(a['sf_prior_mean']), dp(a['sf_prior_sigma']),
-            a['reference_compat'])
+            a['reference_compat'], a['loss_type'])
         h = ctypes.c_void_p()
         _lib.check(lib.sbm_project_load(self._model.device_model.handle, ctypes.byref(desc), ctypes.byref(h)),
                    'sbm_project_load')
@@ -400,7 +407,7 @@ class Project(object):
         _, p_mean, p_sigma, _ = self._prior_rows()
         _, s_mean, s_sigma, _ = self._sf_prior_rows()
         mean = np.concatenate([self._rows['data'], p_mean, s_mean])
-        std = np.concatenate([self._rows['sigma'], p_sigma, s_sigma])
+        std = np.concatenate([self.descriptor_arrays()['row_sigma'], p_sigma, s_sigma])
         tp = np.concatenate([self._rows['t_meas'], np.full(len(p_mean) + len(s_mean), np.nan)])
         return pd.DataFrame({'mean': mean, 'std': std, 'timepoints': tp},
                             index=pd.MultiIndex.from_tuples(labels))

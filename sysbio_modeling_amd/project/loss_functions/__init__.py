@@ -1,3 +1,5 @@
-from .squared_loss import SquareLossFunction, LinearScaleFactor
+from .squared_loss import (SquareLossFunction, LogSquareLossFunction, NormalizedSquareLossFunction,
+                           LinearScaleFactor, LogScaleFactor)
 
-__all__ = ['SquareLossFunction', 'LinearScaleFactor']
+__all__ = ['SquareLossFunction', 'LogSquareLossFunction', 'NormalizedSquareLossFunction',
+           'LinearScaleFactor', 'LogScaleFactor']

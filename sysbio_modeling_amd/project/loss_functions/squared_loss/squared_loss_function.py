@@ -13,9 +13,8 @@ from .linear_scale_factor import LinearScaleFactor
 
 
 class SquareLossFunction(object):
-    # Project checks hasattr(loss_function, 'scale_factors') on the CLASS
-    # (reference project/base_project.py:69-76)
-    scale_factors = None
+    loss_type = 0                    # SBM_LOSS_SQUARE (include/sbm.h)
+    normalize_sigma_by_mean = False  # NormalizedSquareLossFunction sets this
 
     def __init__(self, sf_groups=None, sf_type=LinearScaleFactor):
         self._scale_factors = OrderedHashDict()

@@ -555,3 +555,60 @@ def test_config4_full_size(gpu_models, zoo):
         Jref = po.calc_project_jacobian(thetas[v])
         assert np.allclose(R[v].cpu().numpy(), ref, rtol=1e-7, atol=2e-7)
         assert np.allclose(J[v].cpu().numpy(), Jref, rtol=1e-6, atol=1e-6 * np.max(np.abs(Jref)))
+
+
+# ---------------------------------------------------------------------------
+# next row f3: log-square and normalized losses
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('loss', ['log', 'normalized'])
+@pytest.mark.parametrize('compat', [True, False])
+def test_project_other_losses_vs_oracle(gpu_models, zoo, loss, compat):
+    from oracle import odeint_oracle as oo
+    from oracle.project_oracle import ProjectOracle
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    from sysbio_modeling_amd.project.loss_functions import LogSquareLossFunction, NormalizedSquareLossFunction
+    gm = zoo('michaelis_menten')
+    p_true = np.array([0.05, 0.3, 0.4, 0.05, 0.02])
+    t = np.linspace(0, 60, 13)
+    grid = np.linspace(0, 60, 1000)
+    y = oo.simulate(gm, p_true, grid)[np.searchsorted(grid, t)]
+    rng = np.random.default_rng(12)
+
+    def exps():
+        r = np.random.default_rng(12)
+        a = TimecourseMeasurement('S', 3.0 * y[:, 0] * (1 + 0.05 * r.standard_normal(13)) + 1e-3, t.copy(),
+                                  0.1 * np.abs(y[:, 0]) + 0.05)
+        b = TimecourseMeasurement('P', 0.5 * y[:, 1] * (1 + 0.05 * r.standard_normal(13)) + 1e-3, t.copy(),
+                                  0.1 * np.abs(y[:, 1]) + 0.05)
+        return [Experiment('e1', [a, b]), Experiment('e2', [TimecourseMeasurement('Tot', y.sum(axis=1) + 0.01, t.copy())])]
+    mapping = {'S': ('direct', 0), 'P': ('direct', 1), 'Tot': ('sum', [0, 1])}
+    cls = LogSquareLossFunction if loss == 'log' else NormalizedSquareLossFunction
+    with pytest.warns(UserWarning):
+        proj = Project(gpu_models('michaelis_menten'), exps(), {}, mapping, sf_groups=['S', 'P'], loss_function=cls,
+                       reference_compat=compat)
+    po = ProjectOracle(gm, exps(), {}, mapping, sf_groups=['S', 'P'], reference_compat=compat, loss=loss)
+    for obj in (proj, po):
+        obj.set_scale_factor_log_prior('S', np.log(2.5), 0.3)
+        obj.set_parameter_log_prior('km', 'Global', np.log(0.2), 1.0)
+    thetas = np.log(p_true)[None, :] + 0.2 * rng.standard_normal((4, 5))
+    out = proj.evaluate_batch(thetas, jacobian=True, want=('jacobian', 'gradient', 'sf_gradient'))
+    assert out['status'].tolist() == [0] * 4
+    for v in range(4):
+        ref, sims, B = po.residuals(thetas[v], return_parts=True)
+        Jref = po.calc_project_jacobian(thetas[v])
+        assert np.allclose(out['sf'][v], B, rtol=1e-8)
+        assert np.allclose(out['residuals'][v], ref, rtol=1e-7, atol=1e-7)
+        assert np.allclose(out['jacobian'][v], Jref, rtol=1e-6, atol=1e-7 * np.max(np.abs(Jref)))
+    if not compat:
+        # with J divided by sigma the gradient is the true derivative of 0.5*sum r^2
+        g = rc.central_fd_jacobian(lambda x: np.array([proj.calc_sum_square_residuals(x)]), thetas[0])[0]
+        assert np.allclose(out['gradient'][0], g, rtol=1e-5, atol=1e-6 * np.max(np.abs(g)))
+    # the reference refuses non-positive data under the log loss (log_squared_loss_function.py:55-56)
+    if loss == 'log':
+        bad = [Experiment('e', [TimecourseMeasurement('S', np.array([0.0, 1.0, 2.0]), np.array([1.0, 2.0, 3.0]))])]
+        with pytest.warns(UserWarning):
+            pb = Project(gpu_models('michaelis_menten'), bad, {}, {'S': ('direct', 0)}, loss_function=cls)
+        with pytest.raises(ValueError, match="smaller or equal to zero"):
+            pb.residuals(np.log(p_true))

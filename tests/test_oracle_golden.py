@@ -270,3 +270,62 @@ def test_loss_scale_factor_prior_residual():
     po.sf_priors = {0: (1.0, 2.0)}                                       # :208
     res = po.residuals(np.zeros(1))
     assert np.allclose(res[-1], (np.log(5) - 1) / 2.0)                   # :232-233
+
+
+# ---------------------------------------------------------------------------
+# log-square and normalized losses (tests/test_Loss_Functions.py:166-194, 235-312)
+# ---------------------------------------------------------------------------
+def test_log_loss_residuals_identities():
+    rows, sims = _lin_square_rows()
+    keep = sims != 0                                                     # :170-172
+    rows = [r for r, k in zip(rows, keep) if k]
+    sims = sims[keep]
+    rows = [(r[0], r[1], r[2] / 2.3, r[3], r[4]) for r in rows]           # :176-177
+    po = _RowsOnlyOracle(rows, sims, None, [], 1)
+    po.loss = 'log'
+    assert np.allclose(po.residuals(np.zeros(1)), np.log(2.3))           # :182-184
+    po = _RowsOnlyOracle(rows, sims, None, ['Lin', 'Square'], 1)
+    po.loss = 'log'
+    res, _, B = po.residuals(np.zeros(1), return_parts=True)
+    assert np.allclose(res, 0) and np.allclose(B, 1 / 2.3)               # :190-194
+
+
+def test_log_loss_jacobian_identities():
+    t = np.linspace(0, 11, 11)                                           # :253
+    p1 = np.array([0.3, 0.5, 1.3])
+
+    def model_fcn(p):
+        return p[0] + t * p[2] * p[1] ** 2                               # :238-241
+
+    jac = np.stack([np.ones_like(t), 2 * t * p1[2] * p1[1], t * p1[1] ** 2], axis=1)     # :243-249
+    rng = np.random.default_rng(4)
+    data = model_fcn(p1) * 5 + np.abs(rng.standard_normal(11))           # :267-269
+    rows = [(0, 'Val', d, 1.0, tt) for d, tt in zip(data, t)]
+
+    def mk(p, J=None, groups=('Val',)):
+        o = _RowsOnlyOracle(rows, model_fcn(p), J, list(groups), 3)
+        o.loss = 'log'
+        return o
+
+    B, dB, *_ = mk(p1, jac)._sf(rows, model_fcn(p1), jac)
+    num = rc.central_fd_jacobian(lambda p: np.array([mk(p).residuals(np.zeros(3), return_parts=True)[2][0]]), p1)[0]
+    assert np.allclose(num, dB[0], rtol=0.01)                            # :281-284
+    Jnum = rc.central_fd_jacobian(lambda p: mk(p).residuals(np.zeros(3)), p1)
+    assert np.allclose(mk(p1, jac).calc_project_jacobian(np.zeros(3)), Jnum, rtol=0.01)   # :295
+    # no scale factors: J / sim (:67-69)
+    assert np.allclose(mk(p1, jac, groups=()).calc_project_jacobian(np.zeros(3)), jac / model_fcn(p1)[:, None])
+
+
+def test_normalized_loss_identity():
+    """Normalized residuals x measurement mean == plain residuals (:297-312)."""
+    rng = np.random.default_rng(6)
+    noise = rng.standard_normal(202)
+    rows, sims = _lin_square_rows(noise=noise)
+    rows = [r for r in rows if r[2] != 0]
+    sims_nz = np.array([s for s, r in zip(sims, _lin_square_rows(noise=noise)[0]) if r[2] != 0])
+    plain = _RowsOnlyOracle(rows, sims_nz, None, [], 1).residuals(np.zeros(1))
+    # the oracle applies sigma *= mean when it builds rows(); emulate that on the hand-built rows
+    nrows = [(r[0], r[1], r[2], r[3] * r[2], r[4]) for r in rows]
+    norm = _RowsOnlyOracle(nrows, sims_nz, None, [], 1).residuals(np.zeros(1))
+    d = np.array([r[2] for r in rows])
+    assert np.allclose(norm * d, plain)
