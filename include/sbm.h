@@ -221,6 +221,48 @@ int sbm_jacobian_batch(sbm_project* p, const double* Theta_dev, int32_t V,
  * grown on demand, freed at unload) */
 int64_t sbm_project_scratch_bytes(const sbm_project* p, int32_t V, int32_t with_sens);
 
+/* ---- loss functions on caller-supplied simulations -------------------- */
+/* The reference's loss classes are also callable on hand-built frames
+ * (SquareLossFunction.residuals / .jacobian / .evaluate,
+ * LossFunctionWithScaleFactors.update_scale_factors / .scale_sim_values /
+ * .update_sf_priors_residuals / .update_sf_priors_gradient,
+ * squared_loss_function.py:23-108, abstract_loss_function.py:47-120,
+ * log_squared_loss_function.py:28-98).  This entry runs the same assembly
+ * kernel as sbm_residuals_batch on V stacked frames whose 'mean' columns the
+ * caller supplies, so those methods keep working without an integrator. */
+typedef struct sbm_loss_desc {
+  int32_t n_rows;           /* R: rows of the simulations frame without "~~SF_Prior" rows */
+  int32_t n_params;         /* q: columns of the simulations Jacobian (0 without one) */
+  int32_t n_sf_groups;      /* G */
+  int32_t n_sf_prior_rows;  /* appended after the R rows, as in sbm_project_desc */
+  int32_t loss_type;        /* SBM_LOSS_* */
+  int32_t reference_compat; /* 1: Jacobian rows not divided by sigma (see sbm_project_desc) */
+  const double* row_data;   /* [R] measurement mean */
+  const double* row_sigma;  /* [R] measurement std (non-zero) */
+  const int32_t* row_sf;    /* [R] scale-factor group or -1 */
+  const int32_t* row_plain; /* [R] nullable; 1 = "~Prior" row: (s - d)/sigma even under the
+                               log loss (log_squared_loss_function.py:33-40 drops them
+                               from the transform) */
+  const int32_t* sf_prior_group; /* [n_sf_prior_rows] */
+  const double* sf_prior_mean;
+  const double* sf_prior_sigma;
+} sbm_loss_desc;
+
+/* All pointers are HOST memory (frames live on the host); staged through the
+ * context's stream, synchronous on return.
+ * sims   [V][R]               in
+ * Jm     [V][R][q]            in, nullable: d sim / d theta (simulations_jacobian)
+ * R      [V][R + n_sf_prior]  out residuals; all inf where a frame holds NaN (or a
+ *                             non-positive simulation under the log loss)
+ * J      [V][R + n_sf_prior][q] out, nullable (needs Jm)
+ * sf     [V][G]               out, nullable
+ * sf_grad[V][G][q]            out, nullable (needs Jm)
+ * norms  [V]                  out, nullable: sum r^2
+ * status [V]                  out, nullable: 0 or SBM_NON_FINITE */
+int sbm_loss_eval_host(sbm_ctx* ctx, const sbm_loss_desc* desc, int32_t V, const double* sims,
+                       const double* Jm, double* R, double* J, double* sf, double* sf_grad,
+                       double* norms, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,15 @@ class ProjectDesc(ctypes.Structure):
     ]
 
 
+class LossDesc(ctypes.Structure):
+    _fields_ = [
+        ('n_rows', ctypes.c_int32), ('n_params', ctypes.c_int32), ('n_sf_groups', ctypes.c_int32),
+        ('n_sf_prior_rows', ctypes.c_int32), ('loss_type', ctypes.c_int32), ('reference_compat', ctypes.c_int32),
+        ('row_data', c_double_p), ('row_sigma', c_double_p), ('row_sf', c_int32_p), ('row_plain', c_int32_p),
+        ('sf_prior_group', c_int32_p), ('sf_prior_mean', c_double_p), ('sf_prior_sigma', c_double_p),
+    ]
+
+
 # every symbol include/sbm.h declares: (restype, argtypes)
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -65,6 +74,7 @@ SIGNATURES = {
     'sbm_residuals_batch': (ctypes.c_int, [_vp, _vp, _i32, _opts_p, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sbm_jacobian_batch': (ctypes.c_int, [_vp, _vp, _i32, _opts_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sbm_project_scratch_bytes': (ctypes.c_int64, [_vp, _i32, _i32]),
+    'sbm_loss_eval_host': (ctypes.c_int, [_vp, ctypes.POINTER(LossDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

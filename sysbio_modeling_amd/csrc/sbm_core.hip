@@ -384,6 +384,10 @@ struct AssembleArgs {
   double* Jmodel;             // [V][R][q]     nullable
   double* grad;               // [V][q]        nullable
   double* sf_grad;            // [V][G][q]     nullable
+  // direct mode (sbm_loss_eval): caller-supplied simulations / model Jacobian instead of Y / S
+  const double* sims_in;      // [V][R]        nullable
+  const double* Jm_in;        // [V][R][q]     nullable
+  const int32_t* row_plain;   // [R] nullable: 1 = row keeps the plain (s - d)/sigma form under the log loss
 };
 
 // One block (256 threads) per parameter vector.
@@ -406,7 +410,7 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   __syncthreads();
   // status of the vector = worst status of its trajectories
   int st = 0, steps = 0;
-  for (int e = tid; e < E; e += blockDim.x) {
+  for (int e = tid; a.traj_status && e < E; e += blockDim.x) {
     st = max(st, a.traj_status[(size_t)v * E + e]);
     steps += a.traj_steps ? a.traj_steps[(size_t)v * E + e] : 0;
   }
@@ -418,13 +422,18 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
 
   // ---- 1. sample + map: sims[r] = sum_{var in vars(r)} Y[traj][tidx][var] ----
   for (int r = tid; r < R; r += blockDim.x) {
-    const int e = a.row_exp[r];
-    const size_t base = (((size_t)v * E + e) * a.n_t + a.row_tidx[r]) * a.NV;
     double s = 0.0;
-    for (int k = a.row_var_off[r]; k < a.row_var_off[r + 1]; ++k) s += a.Y[base + a.row_vars[k]];
+    if (a.sims_in) {
+      s = a.sims_in[(size_t)v * R + r];
+    } else {
+      const int e = a.row_exp[r];
+      const size_t base = (((size_t)v * E + e) * a.n_t + a.row_tidx[r]) * a.NV;
+      for (int k = a.row_var_off[r]; k < a.row_var_off[r + 1]; ++k) s += a.Y[base + a.row_vars[k]];
+    }
     s_sim[r] = s;
     // NaN simulations -> inf rows; the log loss cannot take a non-positive simulation either
-    if (!(s == s) || (a.loss == SBM_LOSS_LOG_SQUARE && !(s > 0.0))) atomicMax(&s_bad, (int)SBM_NON_FINITE);
+    const bool logrow = a.loss == SBM_LOSS_LOG_SQUARE && !(a.row_plain && a.row_plain[r]);
+    if (!(s == s) || (logrow && !(s > 0.0))) atomicMax(&s_bad, (int)SBM_NON_FINITE);
   }
   __syncthreads();
   const int bad = s_bad;
@@ -483,8 +492,9 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
     if (r < R) {
       const int g = a.row_sf[r];
       const double B = g >= 0 ? s_B[g] : 1.0;
-      res = (a.loss == SBM_LOSS_LOG_SQUARE) ? (log(B * s_sim[r]) - log(a.row_data[r])) / a.row_sigma[r]
-                                            : (B * s_sim[r] - a.row_data[r]) / a.row_sigma[r];
+      const bool logrow = a.loss == SBM_LOSS_LOG_SQUARE && !(a.row_plain && a.row_plain[r]);
+      res = logrow ? (log(B * s_sim[r]) - log(a.row_data[r])) / a.row_sigma[r]
+                   : (B * s_sim[r] - a.row_data[r]) / a.row_sigma[r];
       s_res[r] = res;
     } else if (r < R + a.NPR) {
       const int k = r - R;
@@ -498,7 +508,7 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   }
   nrm = block_sum(nrm, s_red);
   if (a.norms && tid == 0) a.norms[v] = nrm;
-  if (!a.J && !a.Jmodel && !a.grad) return;
+  if (!a.J && !a.Jmodel && !a.grad && !a.sf_grad) return;
 
   // ---- 4. model Jacobian with the log-parameter chain rule (base_project.py:450-455,482-485):
   //      Jm[r][c] = exp(theta_c) * sum_{model params m of experiment e reading slot c} sum_{var in vars(r)} S[var][m]
@@ -520,20 +530,24 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   for (int c0 = 0; c0 < q; c0 += cw) {
     const int c = c0 + cl;
     if (c >= q || rl >= rpp) continue;
-    const double dth = exp(th[c]);
+    const double dth = a.Jm_in ? 1.0 : exp(th[c]);
     int gcur = -1;
     double jde = 0.0, jds = 0.0;
     for (int r = rl; r < R; r += rpp) {
-      const int e = a.row_exp[r];
-      const size_t base = ((((size_t)v * E + e) * a.n_t + a.row_tidx[r]) * a.NV) * a.NK;
       double jm = 0.0;
-      for (int k = a.inv_ptr[e * (q + 1) + c]; k < a.inv_ptr[e * (q + 1) + c + 1]; ++k) {
-        const int sc = a.sens_col[a.inv_m[k]];
-        if (sc < 0) continue;
-        for (int kk = a.row_var_off[r]; kk < a.row_var_off[r + 1]; ++kk)
-          jm += a.S[base + (size_t)a.row_vars[kk] * a.NK + sc];
+      if (a.Jm_in) {
+        jm = a.Jm_in[((size_t)v * R + r) * q + c];
+      } else {
+        const int e = a.row_exp[r];
+        const size_t base = ((((size_t)v * E + e) * a.n_t + a.row_tidx[r]) * a.NV) * a.NK;
+        for (int k = a.inv_ptr[e * (q + 1) + c]; k < a.inv_ptr[e * (q + 1) + c + 1]; ++k) {
+          const int sc = a.sens_col[a.inv_m[k]];
+          if (sc < 0) continue;
+          for (int kk = a.row_var_off[r]; kk < a.row_var_off[r + 1]; ++kk)
+            jm += a.S[base + (size_t)a.row_vars[kk] * a.NK + sc];
+        }
+        jm *= dth;
       }
-      jm *= dth;
       if (Jm) Jm[(size_t)r * q + c] = jm;
       if (Jv) Jv[(size_t)r * q + c] = jm;
       const int g = a.row_sf[r];
@@ -585,7 +599,7 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
       if (r < R) {
         const int g = a.row_sf[r];
         val = Jv[i];
-        if (a.loss == SBM_LOSS_LOG_SQUARE) {
+        if (a.loss == SBM_LOSS_LOG_SQUARE && !(a.row_plain && a.row_plain[r])) {
           // log_squared_loss_function.py:66-98: J/s (+ (dB/dtheta)/B for rows with a scale factor)
           val = val / s_sim[r];
           if (g >= 0) val += s_dB[g * q + c] / s_B[g];
@@ -749,6 +763,17 @@ extern "C" int64_t sbm_project_scratch_bytes(const sbm_project* p, int32_t V, in
   return b;
 }
 
+static int launch_assemble(const AssembleArgs& g, int V, hipStream_t s, const char* who) {
+  const int Gn = g.G > 0 ? g.G : 1;
+  const int cw_ = g.q < 256 ? g.q : 256, rpp_ = 256 / cw_;
+  const size_t lds = sizeof(double) * ((size_t)2 * g.R + 3 * Gn + 4 + (size_t)Gn * g.q + (size_t)2 * Gn * rpp_ * g.q);
+  if (lds > 160 * 1024) return sbm_fail(SBM_E_ARG, "%s: project too large for the assembly kernel (%zu B of LDS)", who, lds);
+  if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_assemble, dim3(V), dim3(256), lds, s, g);
+  SBM_HIP(hipGetLastError());
+  return 0;
+}
+
 static int project_run(sbm_project* p, const double* Theta, int V, const sbm_integrator_opts* opts, bool sens,
                        double* sims, double* Rout, double* J, double* Jmodel, double* sf, double* sf_grad, double* norms,
                        double* grad, int32_t* status, int32_t* n_steps, const char* who) {
@@ -805,14 +830,7 @@ static int project_run(sbm_project* p, const double* Theta, int V, const sbm_int
   g.sims = sims ? sims : p->sims.p; g.Rout = Rout; g.sf = sf; g.norms = norms; g.status = status; g.n_steps = n_steps;
   g.J = sens ? J : nullptr; g.Jmodel = sens ? Jmodel : nullptr; g.grad = sens ? grad : nullptr;
   g.sf_grad = sens ? sf_grad : nullptr;
-  const int Gn = p->G > 0 ? p->G : 1;
-  const int cw_ = p->q < 256 ? p->q : 256, rpp_ = 256 / cw_;
-  const size_t lds = sizeof(double) * ((size_t)2 * p->R + 3 * Gn + 4 + (size_t)Gn * p->q + (size_t)2 * Gn * rpp_ * p->q);
-  if (lds > 160 * 1024) return sbm_fail(SBM_E_ARG, "%s: project too large for the assembly kernel (%zu B of LDS)", who, lds);
-  if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_assemble, dim3(V), dim3(256), lds, s, g);
-  SBM_HIP(hipGetLastError());
-  return 0;
+  return launch_assemble(g, V, s, who);
 }
 
 extern "C" int sbm_residuals_batch(sbm_project* p, const double* Theta, int32_t V, const sbm_integrator_opts* opts,
@@ -829,4 +847,79 @@ extern "C" int sbm_jacobian_batch(sbm_project* p, const double* Theta, int32_t V
   if (grad && !J) return sbm_fail(SBM_E_ARG, "sbm_jacobian_batch: grad needs J");
   return project_run(p, Theta, V, opts, true, sims, Rout, J, Jmodel, sf, sf_grad, norms, grad, status, n_steps,
                      "sbm_jacobian_batch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss functions on caller-supplied simulations (the reference's frame-level API, a13):
+// the same assembly kernel, reading sims / the model Jacobian from the caller instead of Y / S.
+// ---------------------------------------------------------------------------------------------
+extern "C" int sbm_loss_eval_host(sbm_ctx* ctx, const sbm_loss_desc* d, int32_t V, const double* sims, const double* Jm,
+                                  double* Rout, double* J, double* sf, double* sf_grad, double* norms, int32_t* status) {
+  const char* who = "sbm_loss_eval_host";
+  if (!ctx || !d || !sims || !Rout) return sbm_fail(SBM_E_ARG, "%s: NULL argument", who);
+  const int R = d->n_rows, q = d->n_params, G = d->n_sf_groups, NSP = d->n_sf_prior_rows;
+  if (V < 0 || R <= 0 || q < 0 || G < 0 || NSP < 0) return sbm_fail(SBM_E_ARG, "%s: bad sizes V=%d R=%d q=%d G=%d", who, V, R, q, G);
+  if (d->loss_type != SBM_LOSS_SQUARE && d->loss_type != SBM_LOSS_LOG_SQUARE)
+    return sbm_fail(SBM_E_ARG, "%s: unknown loss_type %d", who, d->loss_type);
+  if (!d->row_data || !d->row_sigma || !d->row_sf) return sbm_fail(SBM_E_ARG, "%s: NULL array in descriptor", who);
+  if ((J || sf_grad) && (!Jm || q <= 0)) return sbm_fail(SBM_E_ARG, "%s: J / sf_grad need the model Jacobian", who);
+  if (NSP && (!d->sf_prior_group || !d->sf_prior_mean || !d->sf_prior_sigma)) return sbm_fail(SBM_E_ARG, "%s: NULL sf prior array", who);
+  for (int r = 0; r < R; ++r) {
+    if (d->row_sf[r] >= G) return sbm_fail(SBM_E_ARG, "%s: row %d sf group %d", who, r, d->row_sf[r]);
+    const bool plain = d->row_plain && d->row_plain[r];
+    if (plain && d->row_sf[r] >= 0) return sbm_fail(SBM_E_ARG, "%s: plain row %d cannot carry a scale factor", who, r);
+    if (d->loss_type == SBM_LOSS_LOG_SQUARE && !plain && !(d->row_data[r] > 0.0))
+      return sbm_fail(SBM_E_ARG, "%s: LogSquare loss cannot handle measurements smaller or equal to zero (row %d)", who, r);
+  }
+  for (int k = 0; k < NSP; ++k)
+    if (d->sf_prior_group[k] < 0 || d->sf_prior_group[k] >= G) return sbm_fail(SBM_E_ARG, "%s: sf prior group", who);
+  if (V == 0) return 0;
+  SBM_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int RT = R + NSP, qq = q > 0 ? q : 1;
+  DevBuf<double> b_data, b_sigma, b_spm, b_sps, b_sims, b_Jm, b_R, b_J, b_sf, b_sfg, b_norms;
+  DevBuf<int32_t> b_sfi, b_plain, b_spg, b_status;
+  int bad = 0;
+  bad |= upload(b_data, d->row_data, (size_t)R, s);
+  bad |= upload(b_sigma, d->row_sigma, (size_t)R, s);
+  bad |= upload(b_sfi, d->row_sf, (size_t)R, s);
+  if (d->row_plain) bad |= upload(b_plain, d->row_plain, (size_t)R, s);
+  bad |= upload(b_spg, d->sf_prior_group, (size_t)NSP, s);
+  bad |= upload(b_spm, d->sf_prior_mean, (size_t)NSP, s);
+  bad |= upload(b_sps, d->sf_prior_sigma, (size_t)NSP, s);
+  bad |= upload(b_sims, sims, (size_t)V * R, s);
+  if (Jm) bad |= upload(b_Jm, Jm, (size_t)V * R * q, s);
+  bad |= b_R.reserve((size_t)V * RT) | b_sf.reserve((size_t)V * (G ? G : 1)) | b_norms.reserve(V) | b_status.reserve(V);
+  if (J) bad |= b_J.reserve((size_t)V * RT * qq);
+  if (Jm) bad |= b_sfg.reserve((size_t)V * (G ? G : 1) * qq);
+  int rc = 0;
+  if (bad) rc = sbm_fail(SBM_E_HIP, "%s: device allocation / upload failed", who);
+  if (!rc) {
+    AssembleArgs g;
+    memset(&g, 0, sizeof(g));
+    g.E = 1; g.q = qq; g.R = R; g.G = G; g.NPR = 0; g.NSP = NSP;
+    g.compat = d->reference_compat; g.loss = d->loss_type;
+    g.row_sf = b_sfi.p; g.row_data = b_data.p; g.row_sigma = b_sigma.p; g.row_plain = d->row_plain ? b_plain.p : nullptr;
+    g.sfp_group = b_spg.p; g.sfp_mean = b_spm.p; g.sfp_sigma = b_sps.p;
+    g.sims_in = b_sims.p; g.Jm_in = Jm ? b_Jm.p : nullptr;
+    g.Rout = b_R.p; g.sf = b_sf.p; g.norms = b_norms.p; g.status = b_status.p;
+    g.J = J ? b_J.p : nullptr; g.sf_grad = Jm ? b_sfg.p : nullptr;
+    rc = launch_assemble(g, V, s, who);
+  }
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    e = hipMemcpyAsync(Rout, b_R.p, (size_t)V * RT * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && J) e = hipMemcpyAsync(J, b_J.p, (size_t)V * RT * q * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && sf && G) e = hipMemcpyAsync(sf, b_sf.p, (size_t)V * G * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && sf_grad && G) e = hipMemcpyAsync(sf_grad, b_sfg.p, (size_t)V * G * q * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && norms) e = hipMemcpyAsync(norms, b_norms.p, (size_t)V * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && status) e = hipMemcpyAsync(status, b_status.p, (size_t)V * 4, hipMemcpyDeviceToHost, s);
+  }
+  hipError_t e2 = hipStreamSynchronize(s);
+  b_data.release(); b_sigma.release(); b_spm.release(); b_sps.release(); b_sims.release(); b_Jm.release(); b_R.release();
+  b_J.release(); b_sf.release(); b_sfg.release(); b_norms.release(); b_sfi.release(); b_plain.release(); b_spg.release();
+  b_status.release();
+  if (rc) return rc;
+  if (e != hipSuccess || e2 != hipSuccess) return sbm_fail(SBM_E_HIP, "%s: %s", who, hipGetErrorString(e != hipSuccess ? e : e2));
+  return 0;
 }

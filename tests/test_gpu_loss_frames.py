@@ -1,0 +1,238 @@
+"""The reference's tests/test_Loss_Functions.py, restated against this package's loss classes.
+
+Those tests call the loss objects on hand-built (experiment, measure)-indexed frames, without a
+Project or an integrator.  Here the same methods run the assembly kernel on the device through
+``sbm_loss_eval_host`` (include/sbm.h); every case is checked against the reference's asserted
+identity (cited line) AND against the oracle's rows-only restatement on the same inputs."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests import reference_cases as rc
+from tests.loss_cases import RowsOnlyOracle, lin_square_rows
+from sysbio_modeling_amd.project.loss_functions.squared_loss import (SquareLossFunction, LogSquareLossFunction,
+                                                                    NormalizedSquareLossFunction)
+
+pytestmark = pytest.mark.gpu
+
+
+def _lin_square_frame():
+    """setUpClass, test_Loss_Functions.py:19-32."""
+    t = np.linspace(0, 100, 101)
+    sim = pd.DataFrame({'mean': np.concatenate([2 * t, t ** 2]), 'timecourse': np.concatenate([t, t])})
+    sim.index = pd.MultiIndex.from_tuples([('Experiment 1', 'Lin')] * 101 + [('Experiment 2', 'Square')] * 101)
+    return sim
+
+
+def _measures(sim, scale=None):
+    m = sim.copy()
+    m.insert(1, 'std', np.ones(len(m)))
+    for name, f in (scale or {}).items():
+        sel = [ix[1] == name for ix in m.index]
+        m.loc[sel, 'mean'] *= f
+    return m
+
+
+def _oracle_rows(measures):
+    exps = {}
+    return [(exps.setdefault(ix[0], len(exps)), ix[1], d, s, t) for ix, d, s, t in
+            zip(measures.index, measures['mean'].values, measures['std'].values, measures['timecourse'].values)]
+
+
+def test_no_scale_factors_loss():
+    """:34-56."""
+    sim = _lin_square_frame()
+    lf = SquareLossFunction()
+    measures = _measures(sim)
+    rng = np.random.default_rng(0)
+    noise = rng.standard_normal(len(measures))
+    measures['mean'] -= noise
+    res = lf.residuals(sim, measures)
+    assert np.allclose(noise, res)
+    assert abs(0.5 * np.sum(noise ** 2) - lf.evaluate(sim, measures)) < 1e-5
+    measures['std'] = np.abs(rng.standard_normal(len(measures))) + 0.05
+    res = lf.residuals(sim, measures)
+    assert np.allclose((sim['mean'] - measures['mean']) / measures['std'], res)
+    po = RowsOnlyOracle(_oracle_rows(measures), sim['mean'].values, None, [], 1)
+    assert np.allclose(res, po.residuals(np.zeros(1)), rtol=1e-13, atol=1e-13)
+    assert list(res.index) == list(sim.index)
+
+
+def test_scale_factors_loss():
+    """:58-80."""
+    sim = _lin_square_frame()
+    lf = SquareLossFunction(sf_groups=['Lin', 'Square'])
+    measures = _measures(sim, {'Lin': 2.0, 'Square': 3.6})
+    lf.update_scale_factors(sim, measures)
+    assert lf.scale_factors['Lin'].sf == 2.0
+    assert lf.scale_factors['Square'].sf == pytest.approx(3.6, abs=1e-14)
+    scaled = lf.scale_sim_values(sim)
+    assert np.allclose(measures['mean'], scaled['mean'])
+    assert np.array_equal(scaled['timecourse'], sim['timecourse'])
+    res = lf.residuals(sim, measures)
+    assert np.allclose(res, 0)
+
+
+def test_nan_simulations_give_inf():
+    """squared_loss_function.py:28-32,46-50."""
+    sim = _lin_square_frame()
+    measures = _measures(sim, {'Lin': 2.0})
+    sim.iloc[7, 0] = np.nan
+    for lf in (SquareLossFunction(), SquareLossFunction(sf_groups=['Lin'])):
+        res = lf.residuals(sim, measures)
+        assert np.all(np.isinf(res))
+    jac = pd.DataFrame(np.ones((len(sim), 2)), columns=['a', 'b'], index=sim.index)
+    out = SquareLossFunction(sf_groups=['Lin']).jacobian(sim, measures, jac)
+    assert np.all(np.isinf(out.values))
+    assert np.all(np.isinf(SquareLossFunction().jacobian(sim, measures, jac).values))
+
+
+def _sine_case():
+    t = np.linspace(0, 10, 11)                                           # :109
+    p1 = np.array([0.3, 0.5, 1.3])
+
+    def model_fcn(p):
+        return p[0] * np.sin(p[1] * t) - p[2] * t ** 2
+
+    jac1 = np.stack([np.sin(p1[1] * t), p1[0] * t * np.cos(p1[1] * t), -t ** 2], axis=1)
+
+    def frame(p):
+        f = pd.DataFrame({'mean': model_fcn(p), 'timecourse': t})
+        f.index = pd.MultiIndex.from_tuples([('Experiment_1', 'Val')] * len(t))
+        return f
+
+    return t, p1, model_fcn, jac1, frame
+
+
+def test_square_loss_jacobian():
+    """:94-164."""
+    t, p1, model_fcn, jac1, frame = _sine_case()
+    sim = frame(p1)
+    jac = pd.DataFrame(jac1, columns=['a', 'b', 'c'], index=sim.index)
+    measures = _measures(sim)
+    lf = SquareLossFunction()
+    assert np.array_equal(jac.values, lf.jacobian(sim, measures, jac).values)   # unchanged (:118-121)
+
+    scaled_lf = SquareLossFunction(sf_groups=['Val'])
+    measures['mean'] *= 5
+    measures['mean'] -= np.random.default_rng(1).standard_normal(len(measures))
+
+    def calc_sf(p):
+        scaled_lf.update_scale_factors(frame(p), measures)
+        return np.array([scaled_lf.scale_factors['Val'].sf])
+
+    num_sf_grad = rc.central_fd_jacobian(calc_sf, p1)[0]
+    scaled_lf.update_scale_factors_gradient(sim, measures, jac)
+    sf_grad = scaled_lf.scale_factors['Val'].gradient
+    assert np.allclose(num_sf_grad, sf_grad, rtol=0.01)                         # :144
+
+    num_jac = rc.central_fd_jacobian(lambda p: np.asarray(scaled_lf.residuals(frame(p), measures)), p1)
+    lf_jac = scaled_lf.jacobian(sim, measures, jac)
+    assert np.allclose(lf_jac.values, num_jac, rtol=0.01)                       # :164
+    assert list(lf_jac.columns) == ['a', 'b', 'c']
+
+    po = RowsOnlyOracle(_oracle_rows(measures), sim['mean'].values, jac1, ['Val'], 3)
+    B, dB, *_ = po._sf(po.rows(), sim['mean'].values, jac1)
+    assert np.allclose(sf_grad, dB[0], rtol=1e-12, atol=1e-14)
+    assert np.allclose(lf_jac.values, po.calc_project_jacobian(np.zeros(3)), rtol=1e-12, atol=1e-13)
+
+
+def test_log_loss_residuals():
+    """:166-194."""
+    sim = _lin_square_frame()
+    sim = sim[sim['mean'] != 0]
+    measures = _measures(sim)
+    measures['mean'] /= 2.3
+    sim_copy, measures_copy = sim.copy(), measures.copy()
+    log_lf = LogSquareLossFunction()
+    res = log_lf.residuals(sim, measures)
+    assert np.allclose(res, np.log(2.3))
+    assert sim.equals(sim_copy) and measures.equals(measures_copy)       # inputs untouched (:186-187)
+    log_lf = LogSquareLossFunction(sf_groups=['Lin', 'Square'])
+    log_lf.update_scale_factors(sim, measures)
+    assert np.allclose(log_lf.residuals(sim, measures), 0)
+    assert log_lf.scale_factors['Lin'].sf == pytest.approx(1 / 2.3, rel=1e-13)
+    bad = measures.copy()
+    bad.iloc[3, 0] = 0.0
+    with pytest.raises(Exception, match="smaller or equal to zero"):     # log_squared_loss_function.py:53-54
+        LogSquareLossFunction().residuals(sim, bad)
+
+
+def test_scale_factor_priors():
+    """:196-233."""
+    lf = SquareLossFunction(sf_groups=['Lin', 'Square'])
+    sim = _lin_square_frame()
+    sim = sim[sim['mean'] != 0]
+    measures = _measures(sim)
+    measures['mean'] *= 5
+    lf.set_scale_factor_priors('Lin', 1.0, 2.0)
+    assert lf.scale_factors['Lin'].log_prior == 1.0 and lf.scale_factors['Lin'].log_prior_sigma == 2.0
+    with pytest.raises(KeyError):                                        # no ~~SF_Prior row in the frames (:212-217)
+        lf.residuals(sim, measures)
+    sf_priors = pd.DataFrame({'mean': [1.0], 'timecourse': [np.nan]},
+                             index=pd.MultiIndex.from_tuples([("~~SF_Prior", "~Lin")]))
+    sim = pd.concat([sim, sf_priors], axis=0)
+    measures = _measures(sim)
+    measures['mean'] *= 5
+    measures.loc[("~~SF_Prior", "~Lin"), :] = np.array([1.0, 2.0, np.nan])
+    res = lf.residuals(sim, measures)
+    assert np.allclose(res.iloc[-1], (np.log(5) - 1) / 2.0)              # :232-233
+    assert np.allclose(res.iloc[:-1], 0)
+    # Jacobian row of the prior: (dB/dtheta)/B (linear_scale_factor.py:44-53), against the oracle
+    rng = np.random.default_rng(5)
+    jm = rng.standard_normal((len(sim), 2))
+    jm[-1] = 0.0
+    jac = lf.jacobian(sim, measures, pd.DataFrame(jm, columns=['a', 'b'], index=sim.index))
+    rows = _oracle_rows(measures.iloc[:-1])
+    po = RowsOnlyOracle(rows, sim['mean'].values[:-1], jm[:-1], ['Lin', 'Square'], 2)
+    po.sf_priors = {0: (1.0, 2.0)}
+    assert np.allclose(jac.values, po.calc_project_jacobian(np.zeros(2)), rtol=1e-11, atol=1e-12)
+
+
+def test_log_squared_loss_jacobian():
+    """:235-295."""
+    t = np.linspace(0, 11, 11)
+    p1 = np.array([0.3, 0.5, 1.3])
+
+    def model_fcn(p):
+        return p[0] + t * p[2] * p[1] ** 2
+
+    def frame(p):
+        f = pd.DataFrame({'mean': model_fcn(p), 'timecourse': t})
+        f.index = pd.MultiIndex.from_tuples([('Experiment_1', 'Val')] * len(t))
+        return f
+
+    jac1 = np.stack([np.ones_like(t), 2 * t * p1[2] * p1[1], t * p1[1] ** 2], axis=1)
+    sim = frame(p1)
+    jac = pd.DataFrame(jac1, columns=['a', 'b', 'c'], index=sim.index)
+    measures = _measures(sim)
+    lf = LogSquareLossFunction(sf_groups=['Val'])
+    measures['mean'] *= 5
+    measures['mean'] += np.abs(np.random.default_rng(4).standard_normal(len(measures)))
+
+    def calc_sf(p):
+        lf.update_scale_factors(frame(p), measures)
+        return np.array([lf.scale_factors['Val'].sf])
+
+    num = rc.central_fd_jacobian(calc_sf, p1)[0]
+    lf.update_scale_factors_gradient(sim, measures, jac)
+    assert np.allclose(num, lf.scale_factors['Val'].gradient, rtol=0.01)        # :281-284
+    num_jac = rc.central_fd_jacobian(lambda p: np.asarray(lf.residuals(frame(p), measures)), p1)
+    out = lf.jacobian(sim, measures, jac)
+    assert np.allclose(out.values, num_jac, rtol=0.01)                          # :295
+    po = RowsOnlyOracle(_oracle_rows(measures), sim['mean'].values, jac1, ['Val'], 3)
+    po.loss = 'log'
+    assert np.allclose(out.values, po.calc_project_jacobian(np.zeros(3)), rtol=1e-12, atol=1e-13)
+    # without scale factors: J / sim (log_squared_loss_function.py:67-69)
+    out0 = LogSquareLossFunction().jacobian(sim, measures, jac)
+    assert np.allclose(out0.values, jac1 / model_fcn(p1)[:, None], rtol=1e-14)
+
+
+def test_normalized_loss_function():
+    """:297-312."""
+    sim = _lin_square_frame()
+    measures = _measures(sim)
+    measures['mean'] -= np.random.default_rng(6).standard_normal(len(measures))
+    res = SquareLossFunction().residuals(sim, measures)
+    norm = NormalizedSquareLossFunction().residuals(sim, measures)
+    assert np.allclose(norm * measures['mean'], res)

@@ -52,9 +52,10 @@ def test_struct_layouts_match_header(tmp_path):
 #include <stddef.h>
 #include "sbm.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sbm_integrator_opts), offsetof(sbm_integrator_opts, rtol),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sbm_integrator_opts), offsetof(sbm_integrator_opts, rtol),
          offsetof(sbm_integrator_opts, t0), sizeof(sbm_project_desc), offsetof(sbm_project_desc, pmap),
-         offsetof(sbm_project_desc, reference_compat));
+         offsetof(sbm_project_desc, reference_compat), sizeof(sbm_loss_desc), offsetof(sbm_loss_desc, row_data),
+         offsetof(sbm_loss_desc, sf_prior_sigma));
   return 0;
 }''')
     exe = str(tmp_path / 'layout')
@@ -62,7 +63,8 @@ int main(void) {
     subprocess.check_call(['gcc', '-I', os.path.join(REPO, 'include'), str(src), '-o', exe])
     c = [int(x) for x in subprocess.check_output([exe]).split()]
     py = [ctypes.sizeof(_lib.IntegratorOpts), _lib.IntegratorOpts.rtol.offset, _lib.IntegratorOpts.t0.offset,
-          ctypes.sizeof(_lib.ProjectDesc), _lib.ProjectDesc.pmap.offset, _lib.ProjectDesc.reference_compat.offset]
+          ctypes.sizeof(_lib.ProjectDesc), _lib.ProjectDesc.pmap.offset, _lib.ProjectDesc.reference_compat.offset,
+          ctypes.sizeof(_lib.LossDesc), _lib.LossDesc.row_data.offset, _lib.LossDesc.sf_prior_sigma.offset]
     assert c == py
 
 
