@@ -196,7 +196,7 @@ def main():
             traffic = json.load(fh).get(args.method, {}).get('hbm_bytes_per_launch')
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "sbm_sens_rowlane_kernel<cascade20,%s>" % args.method, "kernel_ms": k_ms,
+                "kernel": "sbm_sens_rowgroup_kernel<cascade20,%s>" % args.method, "kernel_ms": k_ms,
                 "steps_per_launch": k_steps, "algorithmic_bytes_per_step": BYTES_PER_STEP,
                 "kernel_steps_per_s": k_steps / (k_ms * 1e-3),
                 "note": "algorithmic bytes (2*8*820 B per accepted step) / kernel time; the kernel keeps the "
@@ -222,10 +222,14 @@ def main():
             return {"ms": ms, "steps": st, "steps_per_s": st / (ms * 1e-3)}
         rk = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0)
         dp = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+        dp_rl = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant='row_lane')
+        rk_rl = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0, variant='row_lane')
         dp_pw = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant='per_wave')
         rk_pw = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0, variant='per_wave')
         extras = {"sens_rk4_fixed_%d" % args.rk4_steps: time_kernel('sens', rk),
                   "sens_dopri45": time_kernel('sens', dp),
+                  "sens_dopri45_row_lane_variant": time_kernel('sens', dp_rl),
+                  "sens_rk4_fixed_%d_row_lane_variant" % args.rk4_steps: time_kernel('sens', rk_rl),
                   "sens_dopri45_per_wave_variant": time_kernel('sens', dp_pw),
                   "sens_rk4_fixed_%d_per_wave_variant" % args.rk4_steps: time_kernel('sens', rk_pw),
                   "state_only_dopri45_configs1": time_kernel('state', dp),

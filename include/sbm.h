@@ -50,17 +50,22 @@ typedef struct sbm_integrator_opts {
   double t0;         /* time of the initial condition; output times must be >= t0.
                       * odeint takes t_sim[0] for it (model/ode_model.py:122,167);
                       * Project always integrates from 0 (base_project.py:419)     */
-  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE    */
+  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE | _ROW_GROUP */
   int32_t reserved;  /* must be 0                                                       */
 } sbm_integrator_opts;
 
-/* Two implementations of the sensitivity integrator with identical results up to
- * rounding, both one trajectory per wavefront and one sensitivity column per lane:
- * PER_WAVE evaluates f / J_y / J_p on every lane from broadcast operands; ROW_LANE
- * evaluates them once, lane i working on row i (rows of the same kinetic form side
- * by side), and hands them to the columns through LDS.  ROW_LANE needs n_vars <= 64
- * and n_sens <= 64; AUTO picks it when the model's rows fall into few classes. */
-enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2 };
+/* Three implementations of the sensitivity integrator with identical results up to
+ * rounding, all one trajectory per wavefront.  PER_WAVE: one sensitivity column per
+ * lane, f / J_y / J_p evaluated on every lane from broadcast operands.  ROW_LANE:
+ * they are evaluated once, lane i working on row i (rows of the same kinetic form
+ * side by side), and handed to the columns through LDS.  ROW_GROUP: ROW_LANE with
+ * the rows of a column split over several lanes, so that all 64 lanes carry
+ * equations and the Runge-Kutta stages fit the register file.  ROW_LANE / ROW_GROUP
+ * need n_vars <= 64 and n_sens <= 64; AUTO picks ROW_GROUP when the model's rows
+ * fall into few classes and the model generator found a paying split, else ROW_LANE
+ * under the first condition, else PER_WAVE.  A forced variant the model does not
+ * support falls back in the same order. */
+enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2, SBM_VARIANT_ROW_GROUP = 3 };
 
 /* per-trajectory status written next to the results (the reference does not
  * check LSODA failures, model/ode_model.py:122,167; non-zero statuses are what

@@ -125,7 +125,7 @@ def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2}
+VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3}
 
 
 def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None, t0=0.0,

@@ -192,7 +192,7 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
   } else {
     return sbm_fail(SBM_E_ARG, "%s: unknown method %d", who, o->method);
   }
-  if (o->variant < SBM_VARIANT_AUTO || o->variant > SBM_VARIANT_ROW_LANE)
+  if (o->variant < SBM_VARIANT_AUTO || o->variant > SBM_VARIANT_ROW_GROUP)
     return sbm_fail(SBM_E_ARG, "%s: unknown kernel variant %d", who, o->variant);
   return 0;
 }

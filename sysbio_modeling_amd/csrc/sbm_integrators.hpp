@@ -139,6 +139,8 @@ struct SensSystem {
   static constexpr int NVX = M::NV;   // no extra per-lane elements
   static constexpr int NCOL = 1 + M::NK;
   static constexpr int CPL = (NCOL + 63) / 64;
+  static constexpr int NCS = CPL;
+  __device__ __forceinline__ static constexpr int col_of(int c, int) { return c; }
   static constexpr bool kUniform = true;
   const double* __restrict__ p;  // wave-uniform -> scalar loads
   int lane;
@@ -185,6 +187,8 @@ struct StateSystem {
   static constexpr int NV = M::NV;
   static constexpr int NVX = M::NV;
   static constexpr int CPL = 1;
+  static constexpr int NCS = 1;
+  __device__ __forceinline__ static constexpr int col_of(int, int) { return 0; }
   static constexpr bool kUniform = false;
   SbmLdsParams p;
 
@@ -300,7 +304,11 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
 
       // embedded error estimate; ratios and norm in f32 (they only steer the controller)
       const double he1 = hs * E1, he3 = hs * E3, he4 = hs * E4, he5 = hs * E5, he6 = hs * E6, he7 = hs * E7;
-      float colsum[CPL];
+      // one sum of squares per column a lane holds (a lane of the row-group system holds the
+      // rows of several columns next to each other inside one array: Sys::col_of maps them)
+      float colsum[Sys::NCS];
+#pragma unroll
+      for (int c = 0; c < Sys::NCS; ++c) colsum[c] = 0.f;
       float xsum = 0.f;
       auto err_ratio = [&](int c, int i) {
         const double e = fma(he7, k2[c][i],
@@ -310,13 +318,11 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       };
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const float r = err_ratio(c, i);
-          acc = fmaf(r, r, acc);
+          colsum[Sys::col_of(c, i)] = fmaf(r, r, colsum[Sys::col_of(c, i)]);
         }
-        colsum[c] = acc;
 #pragma unroll
         for (int i = NV; i < NVX; ++i) {
           const float r = err_ratio(c, i);
@@ -557,6 +563,8 @@ struct RowLaneSystem {
   static constexpr int NV = M::NV;
   static constexpr int NVX = M::NV + 1;  // column rows + this lane's own state component
   static constexpr int CPL = 1;
+  static constexpr int NCS = 1;
+  __device__ __forceinline__ static constexpr int col_of(int, int) { return 0; }
   SbmRowLaneShared<M>* sh;
   int lane;
   int cls;                       // class of this lane's row, -1 on lanes without a row
@@ -724,6 +732,226 @@ __global__ void __launch_bounds__(64) sbm_sens_rowlane_kernel(sbm_kernel_args a)
   }
 }
 
+// ===========================================================================
+// Row-group sensitivity kernel: the row-lane kernel with the rows of a column split over G lanes.
+//
+// One trajectory per wavefront, as before; the state still lives one component per lane and the
+// row lanes still evaluate f / J_y / J_p by class.  What changes is the distribution of S:
+// lane (g, c') = g*C + c' owns rows [g*RPG, (g+1)*RPG) of the columns c', c'+C, ... (CPL of them),
+// RPG*CPL elements instead of NV.  For the 20-state / 40-parameter cascade that is 14 elements
+// on 60 lanes instead of 20 elements on 40 lanes: fewer instructions per step in proportion and a
+// Runge-Kutta working set that (nearly) fits the 256 architectural VGPRs, so the v_accvgpr
+// traffic of the row-lane kernel goes away.  Price: J_y coefficients are per-lane values now (LDS
+// table JYL instead of v_readlane scalars) and terms that cross a group boundary go through an LDS
+// halo (emit_rowgroup.py).  Still a 64-thread workgroup: wave-local LDS ordering, no barriers.
+// ===========================================================================
+template <class M>
+struct SbmRowGroupShared {
+  // JYL rows: G groups of RPG (the last one padded), then one more all-padding group for the idle
+  // lanes (>= G*C): nothing is ever written there, it stays zero
+  static constexpr int NPAD = M::RG_G * M::RG_RPG;
+  static constexpr int NROWS = NPAD + M::RG_RPG;
+  static constexpr int LS = M::RG_LS;    // A / H are [local row][lane][cc]; element (i, j) at M::rg_pos(i, j)
+  static constexpr int ZPOS = M::RG_RPG * LS;   // a slot of H that stays zero (absent halo terms)
+  double Y[64];                          // stage state, one component per row lane
+  alignas(16) double JYL[NROWS * M::RG_JYS + 2];   // J_y coefficients [row][term] (+ spare slot)
+  alignas(16) double A[M::RG_RPG * LS + 2];        // J_p entries (+ spare slot); idle / padded slots stay 0
+  alignas(16) double H[M::RG_RPG * LS + 4];        // published rows of the stage vector (+ zero slot)
+};
+
+template <class M>
+struct RowGroupSystem {
+  static constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG;
+  static constexpr int NV = M::RG_RPG * M::RG_CPL;   // elements of S this lane integrates
+  static constexpr int NVX = NV + 1;                 // + this lane's own state component
+  static constexpr int CPL = 1;
+  static constexpr int NCS = M::RG_CPL;
+  __device__ __forceinline__ static constexpr int col_of(int, int i) { return i / M::RG_RPG; }
+  static constexpr int NH = M::RG_NHALO > 0 ? M::RG_NHALO : 1;
+  SbmRowGroupShared<M>* sh;
+  int lane, grp, cp;             // lane = grp*C + cp on the active lanes
+  bool active;                   // lane < G*C
+  int cls;
+  int yidx[M::RL_MAXYS];
+  double ps[M::RL_MAXPS];
+  int jypos[M::RL_MAXJY];
+  int apos[M::RL_MAXJP];
+  const double* a_lane;
+  const double* jy_lane;
+  double* h_lane;
+  int hoff[NH];
+
+  __device__ __forceinline__ static void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
+
+  struct Token { double f; };
+  __device__ __forceinline__ Token begin(double t, const double (&z)[1][NVX]) const {
+    Token k;
+    sh->Y[lane] = z[0][NV];
+    lds_order();
+    double ys[M::RL_MAXYS];
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXYS; ++s) ys[s] = sh->Y[yidx[s]];
+    double jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+    k.f = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
+    M::class_dispatch(cls, t, ys, ps, k.f, jy, jp);
+    lds_order();
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) sh->JYL[jypos[s]] = jy[s];
+    lds_order();
+    return k;
+  }
+  __device__ __forceinline__ void finish(const Token& k, double /*t*/, const double (&z)[1][NVX],
+                                         double (&dz)[1][NVX]) const {
+    double zc[NV], dc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) zc[i] = z[0][i];
+    M::publish_rowgroup(h_lane, zc);
+    lds_order();
+    M::apply_rowgroup(a_lane, jy_lane, sh->H, hoff, zc, dc);
+    lds_order();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
+    dz[0][NV] = k.f;
+  }
+  __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
+    const Token k = begin(t, z);
+    finish(k, t, z, dz);
+  }
+  // max( RMS of the state error, max over columns of the column RMS ); a column's sum of squares
+  // is spread over the G lanes cp, C + cp, ...
+  __device__ __forceinline__ float norm(const float (&colsum)[NCS], float xsum) const {
+    float m = 0.f;
+    float bad = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < NCS; ++cc) {
+      float v = active ? colsum[cc] : 0.f;
+      float tot = v;
+#pragma unroll
+      for (int gg = 1; gg < G; ++gg) {
+        int src = lane + gg * C;
+        src = src >= G * C ? src - G * C : src;
+        tot += __shfl(v, active ? src : lane, 64);
+      }
+      const bool has_col = active && (cp + C * cc < M::NK);
+      tot = has_col ? tot : 0.f;
+      bad = (tot != tot) ? 1.f : bad;
+      m = fmaxf(m, (tot != tot) ? 0.f : tot);
+    }
+    xsum = (lane < M::NV) ? xsum : 0.f;
+    bad = (xsum != xsum) ? 1.f : bad;
+    const float mx = sbm_wave_max(m);
+    float xs = (xsum != xsum) ? 0.f : xsum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) xs += __shfl_xor(xs, off, 64);
+    xs = sbm_bcast0f(xs);
+    const float anybad = sbm_wave_max(bad);
+    return anybad > 0.f ? __builtin_nanf("") : sqrtf(fmaxf(mx, xs) * (1.0f / M::NV));
+  }
+  __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
+};
+
+template <class M, int METHOD>
+__global__ void __launch_bounds__(64) sbm_sens_rowgroup_kernel(sbm_kernel_args a) {
+  using Sys = RowGroupSystem<M>;
+  using Sh = SbmRowGroupShared<M>;
+  constexpr int MNV = M::NV, NK = M::NK;
+  constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG, CPL = M::RG_CPL;
+  constexpr int NE = Sys::NV, NVX = Sys::NVX, NPAD = Sh::NPAD;
+  static_assert(MNV <= 64 && G * C <= 64 && C * CPL <= 64 && C * CPL >= NK && NPAD >= MNV, "row-group layout");
+  __shared__ Sh sh;
+  const int traj = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (traj >= a.n_traj) return;
+
+  constexpr int NROWS = Sh::NROWS;
+  constexpr int LS = Sh::LS;
+  for (int i = lane; i < RPG * LS + 2; i += 64) sh.A[i] = 0.0;
+  for (int i = lane; i < RPG * LS + 4; i += 64) sh.H[i] = 0.0;
+  for (int i = lane; i < NROWS * M::RG_JYS + 2; i += 64) sh.JYL[i] = 0.0;
+  sh.Y[lane] = 0.0;
+
+  Sys sys;
+  sys.sh = &sh;
+  sys.lane = lane;
+  sys.active = lane < G * C;
+  sys.grp = sys.active ? lane / C : G;   // idle lanes form the all-padding group: zeros throughout
+  sys.cp = lane - sys.grp * C;
+  const bool has_row = lane < MNV;
+  const int row = has_row ? lane : 0;
+  sys.cls = has_row ? M::rl_class(row) : -1;
+  const double* P = a.P + (size_t)traj * M::NP;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[s] = M::rl_ys(s, row);
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[s] = P[M::rl_ps(s, row)];
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJY; ++s) {
+    const int jp_ = M::rg_jypos(s, row);
+    sys.jypos[s] = (has_row && jp_ < NPAD * M::RG_JYS) ? jp_ : NROWS * M::RG_JYS + 1;   // else: spare slot
+  }
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJP; ++s) {
+    const int ap = M::rl_apos(s, row);                        // row*64 + column; unused slots carry MNV*64
+    sys.apos[s] = (has_row && ap < MNV * 64) ? M::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1;
+  }
+  sys.a_lane = sh.A + CPL * lane;
+  sys.jy_lane = sh.JYL + (sys.grp * RPG) * M::RG_JYS;
+  sys.h_lane = sh.H + CPL * lane;
+#pragma unroll
+  for (int t = 0; t < Sys::NH; ++t) {
+    const int src = (M::RG_NHALO > 0 && sys.active) ? M::rg_hsrc(t, sys.grp) : NPAD;   // NPAD: term absent
+    sys.hoff[t] = src < NPAD ? M::rg_pos(src, sys.cp) : Sh::ZPOS;
+  }
+  __syncthreads();
+
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+
+  // element (r, cc) of this lane = S[grp*RPG + r][cp + C*cc]
+  double z[1][NVX];
+#pragma unroll
+  for (int cc = 0; cc < CPL; ++cc)
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+      const int grow = sys.grp * RPG + r, col = sys.cp + C * cc;
+      const bool valid = sys.active && grow < MNV && col < NK;
+      z[0][r + RPG * cc] = (a.s0 && valid) ? a.s0[grow * NK + col] : 0.0;
+    }
+  z[0][NE] = (a.y0 && has_row) ? a.y0[lane] : 0.0;
+
+  double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * MNV : nullptr;
+  double* St = a.S ? a.S + (size_t)traj * a.n_t * MNV * NK : nullptr;
+  auto store = [&](int io, const double (&zz)[1][NVX]) {
+    if (Yt && has_row) Yt[(size_t)io * MNV + lane] = zz[0][NE];
+    if (St) {
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc)
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+          const int grow = sys.grp * RPG + r, col = sys.cp + C * cc;
+          if (sys.active && grow < MNV && col < NK) St[((size_t)io * MNV + grow) * NK + col] = zz[0][r + RPG * cc];
+        }
+    }
+  };
+
+  SbmTrajOut r;
+  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
+  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+
+  if (lane == 0) {
+    if (a.status) a.status[traj] = r.status;
+    if (a.n_steps) a.n_steps[traj] = r.n_acc;
+    if (a.n_reject) a.n_reject[traj] = r.n_rej;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host-side launcher used by sbm_plugin_main.hip
 // ---------------------------------------------------------------------------
@@ -738,6 +966,18 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     constexpr bool kRowLanePays = kRowLaneOk && (M::RL_NCLASS * 4 <= M::NV + 3);
     const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
                          (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays);
+    // row-group kernel: the row-lane kernel with the rows of a column split over several lanes,
+    // when the emitter found a split that cuts the elements per lane (M::RG_OK)
+    if constexpr (kRowLaneOk && M::RG_OK) {
+      if (a.opts.variant == SBM_VARIANT_ROW_GROUP || (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays)) {
+        dim3 grid(a.n_traj), block(64);
+        if (a.opts.method == SBM_DOPRI45)
+          hipLaunchKernelGGL((sbm_sens_rowgroup_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+        else
+          hipLaunchKernelGGL((sbm_sens_rowgroup_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+        return (int)hipGetLastError();
+      }
+    }
     if constexpr (kRowLaneOk) {
       if (rowlane) {
         dim3 grid(a.n_traj), block(64);

@@ -22,6 +22,7 @@ from sympy.printing.c import C99CodePrinter
 
 from . import sympy_tools
 from . import emit_rowlane
+from . import emit_rowgroup
 
 
 _RCP = sympy.Function('SBM_RCP')
@@ -334,7 +335,8 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     nnz_y, nnz_p = max(len(d.jy), 1), max(len(d.jp), 1)
     L = _fmt_header(spec, "//")
     rl_tables, rl_meta = emit_rowlane.emit_rowlane_tables(spec, d, None)
-    L += ["#pragma once", ""] + rl_tables + [
+    rg_tables, rg_layout = emit_rowgroup.emit_tables(spec, d)
+    L += ["#pragma once", ""] + rl_tables + rg_tables + [
           "struct SbmModel {",
           "  static constexpr int NV = %d;      // state variables" % n,
           "  static constexpr int NP = %d;      // model parameters (length of p)" % spec.n_params,
@@ -422,5 +424,6 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     # ---- row-lane form: SIMD across isomorphic equations (emit_rowlane.py) ----
     L += emit_rowlane.emit_rowlane_members(spec, d, rl_meta,
                                            lambda smap: _ExprPrinter(smap, rcp="SBM_RCP(%s)", lang='hip'))
+    L += [""] + emit_rowgroup.emit_members(spec, d, rg_layout)
     L += ["};", ""]
     return "\n".join(L)

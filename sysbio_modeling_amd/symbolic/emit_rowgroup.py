@@ -1,0 +1,181 @@
+"""Row-group form: the row-lane mapping with the rows of a column split over several lanes.
+
+The row-lane kernel (emit_rowlane.py) keeps one sensitivity column per lane.  A model with
+fewer than 64 columns leaves lanes idle (cascade20: 40 of 64), and every lane carries all NV
+rows of every Runge-Kutta stage vector, which is what overflows the 256 architectural VGPRs.
+Here the lanes of a wavefront form G groups of C lanes; lane (g, c') integrates rows
+[g*RPG, (g+1)*RPG) of the CPL columns c', c'+C, ...: RPG*CPL elements per lane instead of NV
+(cascade20: G=3, C=20, CPL=2, RPG=7 -> 14 elements instead of 20, 60 of 64 lanes busy).
+
+All lanes run the same instruction stream, so "local row r" must look alike in every group:
+
+  * the J_y terms of local row r are the union, over the groups, of the terms of global row
+    g*RPG + r, matched by their cyclic column offset (m - i) mod NV (a feedback from the last
+    to the first species is the cyclic neighbour of a sub-diagonal); a group that lacks a term
+    reads a zero coefficient;
+  * a term whose source row is the same LOCAL row r' in every group is a register operand
+    (z[r']); any other term is a HALO term: the source rows are published to LDS once per
+    stage (``publish_rowgroup``) and read back through a per-lane offset (table RG_HSRC);
+  * coefficients come from the LDS table JYL[row][term] the row lanes fill, read through a
+    per-lane base pointer, so the same static offset serves every group.
+
+LDS layout of the tables A (J_p entries) and H (halo rows): indexed by LOCAL row and LANE,
+[r][lane][cc] with CPL doubles per lane, so element (row i, column j) sits at
+  (i % RPG)*LS + CPL*((i // RPG)*C + j % C) + j // C,      LS = 64*CPL.
+Every lane owns private slots: the 64 lanes of a wave access consecutive CPL*8-byte words (no bank
+conflicts, one ds_read_b128 per local row for CPL = 2), slots of idle lanes and padded rows are
+never written and stay zero.
+
+``plan`` decides whether the form pays at all (RG_OK); the integrator falls back to the
+row-lane kernel otherwise.
+"""
+from __future__ import annotations
+
+
+def plan(n, nk, max_lanes=64):
+    """(G, C, CPL, RPG) minimising the elements per lane, or None when splitting rows does not
+    reduce them by at least 20 %."""
+    if n < 2 or nk < 1 or n > max_lanes:
+        return None
+    best = None
+    for G in range(2, 9):
+        C = max_lanes // G
+        if C < 1:
+            break
+        CPL = -(-nk // C)
+        C = -(-nk // CPL)          # balance the columns over the CPL slots
+        RPG = -(-n // G)
+        if (G - 1) * RPG >= n:     # an empty last group: a smaller G does the same
+            continue
+        elems = RPG * CPL
+        if best is None or elems < best[0]:
+            best = (elems, G, C, CPL, RPG)
+    if best is None or best[0] > 0.8 * n:
+        return None
+    return best[1:]
+
+
+def layout(spec, d):
+    """Term structure of the row-group form.  Returns None when the form does not apply."""
+    n, nk = spec.n_vars, spec.n_sens
+    p = plan(n, nk)
+    if p is None:
+        return None
+    G, C, CPL, RPG = p
+    pattern = []                       # per global row: {cyclic offset: (e_idx, m)}
+    for i in range(n):
+        pattern.append({(m - i) % n: (e_idx, m) for e_idx, m in d.jy_rows[i]})
+    terms = []                         # per local row: list of dict(rel, own=r' or None, halo=t or None)
+    hsrc = []                          # per halo term: [source global row per group] (n_pad = zero row)
+    publish = set()
+    n_pad = G * RPG                    # index of the always-zero row of H
+    for r in range(RPG):
+        rows = [g * RPG + r for g in range(G) if g * RPG + r < n]
+        rels = sorted({rel for i in rows for rel in pattern[i]}, key=lambda x: (x != 0, x))
+        tl = []
+        for rel in rels:
+            own = None
+            srcs = {}
+            for g in range(G):
+                i = g * RPG + r
+                if i < n and rel in pattern[i]:
+                    srcs[g] = pattern[i][rel][1]
+            local = {m - g * RPG for g, m in srcs.items()}
+            if len(local) == 1:
+                rp = next(iter(local))
+                if 0 <= rp < RPG and all(m // RPG == g for g, m in srcs.items()):
+                    own = rp
+            if own is not None:
+                tl.append(dict(rel=rel, own=own, halo=None))
+            else:
+                tl.append(dict(rel=rel, own=None, halo=len(hsrc)))
+                hsrc.append([srcs.get(g, n_pad) for g in range(G)])
+                for m in srcs.values():
+                    publish.add(m % RPG)
+        terms.append(tl)
+    jys = max([len(t) for t in terms] + [1])
+    # where row lane i puts slot s of its class: JYL[i*jys + k]
+    max_jy = max([len(x) for x in d.jy_rows] + [1])
+    spare = n_pad * jys                # one slot past the table
+    jypos = [[spare] * n for _ in range(max_jy)]
+    for i in range(n):
+        r = i % RPG
+        rel_to_k = {t['rel']: k for k, t in enumerate(terms[r])}
+        for s, (e_idx, m) in enumerate(d.jy_rows[i]):
+            jypos[s][i] = i * jys + rel_to_k[(m - i) % n]
+    return dict(G=G, C=C, CPL=CPL, RPG=RPG, LS=64 * CPL, terms=terms, hsrc=hsrc,
+                publish=sorted(publish), jys=jys, jypos=jypos, max_jy=max_jy, n_pad=n_pad)
+
+
+def emit_tables(spec, d):
+    lay = layout(spec, d)
+    if lay is None:
+        return [], None
+    n = spec.n_vars
+    L = ["// row-group tables",
+         "__constant__ short SBM_RG_JYPOS[%d] = {%s};   // [slot][row] -> index into JYL" %
+         (lay['max_jy'] * n, ", ".join(str(v) for slot in lay['jypos'] for v in slot))]
+    nh = max(len(lay['hsrc']), 1)
+    flat = [v for t in lay['hsrc'] for v in t] or [lay['n_pad']] * lay['G']
+    L += ["__constant__ short SBM_RG_HSRC[%d] = {%s};   // [halo term][group] -> source row" %
+          (nh * lay['G'], ", ".join(str(v) for v in flat)), ""]
+    return L, lay
+
+
+def emit_members(spec, d, lay):
+    """Members of ``struct SbmModel``; with ``lay is None`` only RG_OK = false and inert stubs."""
+    n = spec.n_vars
+    if lay is None:
+        return ["  // ---- row-group form: does not pay for this model ----",
+                "  static constexpr bool RG_OK = false;",
+                "  static constexpr int RG_G = 1, RG_C = 64, RG_CPL = 1, RG_RPG = NV, RG_JYS = 1, RG_NHALO = 0, RG_LS = 64;",
+                "  __device__ __forceinline__ static int rg_jypos(int, int) { return 0; }",
+                "  __device__ __forceinline__ static int rg_hsrc(int, int) { return 0; }",
+                "  __device__ __forceinline__ static int rg_pos(int row, int col) { return row * 64 + col; }",
+                "  template <int NZ> __device__ __forceinline__ static void publish_rowgroup(double*, const double (&)[NZ]) {}",
+                "  template <int NZ> __device__ __forceinline__ static void apply_rowgroup(const double*, const double*, const double*,",
+                "      const int (&)[1], const double (&)[NZ], double (&)[NZ]) {}"]
+    G, C, CPL, RPG, jys, LS = lay['G'], lay['C'], lay['CPL'], lay['RPG'], lay['jys'], lay['LS']
+    nh = len(lay['hsrc'])
+    L = ["  // ---- row-group form (sbm_sens_rowgroup_kernel): lane (g, c') = rows [g*RPG, (g+1)*RPG) of",
+         "  //      columns c' + C*cc; element index of (local row r, column slot cc) is r + RPG*cc ----",
+         "  static constexpr bool RG_OK = true;",
+         "  static constexpr int RG_G = %d, RG_C = %d, RG_CPL = %d, RG_RPG = %d, RG_JYS = %d, RG_NHALO = %d;"
+         % (G, C, CPL, RPG, jys, nh),
+         "  static constexpr int RG_LS = %d;   // local-row stride of the A / H tables (doubles): [r][lane][cc]" % LS,
+         "  // position of (row, column) in A / H",
+         "  __device__ __forceinline__ static int rg_pos(int row, int col) {",
+         "    return (row % RG_RPG) * RG_LS + RG_CPL * ((row / RG_RPG) * RG_C + col % RG_C) + col / RG_C;",
+         "  }",
+         "  __device__ __forceinline__ static int rg_jypos(int slot, int row) { return SBM_RG_JYPOS[slot * NV + row]; }",
+         "  __device__ __forceinline__ static int rg_hsrc(int term, int group) { return SBM_RG_HSRC[term * RG_G + group]; }",
+         "  // rows other groups read: h_lane = H + CPL*lane",
+         "  template <int NZ>",
+         "  __device__ __forceinline__ static void publish_rowgroup(double* h_lane, const double (&z)[NZ]) {",
+         "    (void)h_lane; (void)z;"]
+    for r in lay['publish']:
+        for cc in range(CPL):
+            L.append("    h_lane[%d] = z[%d];" % (r * LS + cc, r + RPG * cc))
+    L += ["  }",
+          "  // dz = J_y z + A for the lane's rows of its columns.  a_lane = A + CPL*lane, jy_lane = &JYL[g*RPG][0]",
+          "  // (layout JYL[row][RG_JYS]), h_all = H, hoff[t] = rg_pos(rg_hsrc(t, g), c') or the zero slot RPG*LS.",
+          "  template <int NZ>",
+          "  __device__ __forceinline__ static void apply_rowgroup(const double* a_lane, const double* jy_lane,",
+          "                                                        const double* h_all, const int (&hoff)[%d]," % max(nh, 1),
+          "                                                        const double (&z)[NZ], double (&dz)[NZ]) {",
+          "    (void)jy_lane; (void)h_all; (void)hoff;"]
+    for r in range(RPG):
+        for k, t in enumerate(lay['terms'][r]):
+            L.append("    const double c%d_%d = jy_lane[%d];" % (r, k, r * jys + k))
+            if t['halo'] is not None:
+                for cc in range(CPL):
+                    L.append("    const double h%d_%d_%d = h_all[hoff[%d] + %d];" % (r, k, cc, t['halo'], cc))
+    for cc in range(CPL):
+        for r in range(RPG):
+            expr = "a_lane[%d]" % (r * LS + cc)
+            for k, t in enumerate(lay['terms'][r]):
+                src = ("z[%d]" % (t['own'] + RPG * cc)) if t['own'] is not None else ("h%d_%d_%d" % (r, k, cc))
+                expr = "fma(c%d_%d, %s, %s)" % (r, k, src, expr)
+            L.append("    dz[%d] = %s;" % (r + RPG * cc, expr))
+    L += ["  }"]
+    return L

@@ -4,6 +4,8 @@
 //   h_sens_rhs          eval_jac once, apply_col per column, state in column 0   (per-wave kernel, CPL > 1)
 //   h_sens_rhs_fused    eval_col per column                                      (per-wave kernel, CPL == 1)
 //   h_sens_rhs_rowlane  class_dispatch per row lane + apply_rowlane per column   (row-lane kernel)
+//   h_sens_rhs_rowgroup class_dispatch per row lane + publish/apply_rowgroup per lane (g, c')
+//                       (row-group kernel; returns -1 when the model has no row-group form)
 // Used by tests/test_symbolic.py to pin the HIP text to the Python/C emitters on CPU.
 #include <cmath>
 #define __device__
@@ -89,6 +91,70 @@ void h_sens_rhs_rowlane(const double* y, double t, double* yout, const double* p
     for (int i = 0; i < N; ++i) { z[i] = y[N + i * K + c]; acol[i] = ash[i * 64 + c]; }
     SbmModel::apply_rowlane(jy_names, sj, acol, z, dz);
     for (int i = 0; i < N; ++i) yout[N + i * K + c] = dz[i];
+  }
+}
+
+// The row-group kernel's right-hand side, lane by lane: LDS tables are plain arrays here, the
+// per-lane base pointers / halo offsets are set up exactly as sbm_sens_rowgroup_kernel does.
+int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p) {
+  using M = SbmModel;
+  if constexpr (!M::RG_OK) {
+    (void)y; (void)t; (void)yout; (void)p;
+    return -1;
+  } else {
+    constexpr int N = M::NV, K = M::NK, G = M::RG_G, C = M::RG_C, CPL = M::RG_CPL, RPG = M::RG_RPG, JYS = M::RG_JYS;
+    constexpr int NPAD = G * RPG, NROWS = NPAD + RPG, NE = RPG * CPL;
+    constexpr int NH = M::RG_NHALO > 0 ? M::RG_NHALO : 1;
+    constexpr int LS = M::RG_LS, ZPOS = RPG * LS;
+    static double A[RPG * LS + 2], H[RPG * LS + 4], JYL[NROWS * JYS + 2];
+    for (double& v : A) v = 0.0;
+    for (double& v : H) v = 0.0;
+    for (double& v : JYL) v = 0.0;
+    for (int row = 0; row < N; ++row) {
+      double ys[M::RL_MAXYS], ps[M::RL_MAXPS], f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+      for (int s = 0; s < M::RL_MAXYS; ++s) ys[s] = y[M::rl_ys(s, row)];
+      for (int s = 0; s < M::RL_MAXPS; ++s) ps[s] = p[M::rl_ps(s, row)];
+      for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+      for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
+      M::class_dispatch(M::rl_class(row), t, ys, ps, f, jy, jp);
+      for (int s = 0; s < M::RL_MAXJP; ++s) {
+        const int ap = M::rl_apos(s, row);
+        A[ap < N * 64 ? M::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1] = jp[s];
+      }
+      for (int s = 0; s < M::RL_MAXJY; ++s) {
+        const int jpz = M::rg_jypos(s, row);
+        JYL[jpz < NPAD * JYS ? jpz : NROWS * JYS + 1] = jy[s];
+      }
+      yout[row] = f;
+    }
+    double z[64][NE], dz[64][NE];
+    for (int lane = 0; lane < 64; ++lane) {   // every lane publishes before any lane reads
+      const bool active = lane < G * C;
+      const int g = active ? lane / C : G, cp = lane - g * C;
+      for (int cc = 0; cc < CPL; ++cc)
+        for (int r = 0; r < RPG; ++r) {
+          const int grow = g * RPG + r, col = cp + C * cc;
+          z[lane][r + RPG * cc] = (active && grow < N && col < K) ? y[N + grow * K + col] : 0.0;
+        }
+      M::publish_rowgroup(H + CPL * lane, z[lane]);
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+      const bool active = lane < G * C;
+      const int g = active ? lane / C : G, cp = lane - g * C;
+      int hoff[NH];
+      for (int tt = 0; tt < NH; ++tt) {
+        const int src = (M::RG_NHALO > 0 && active) ? M::rg_hsrc(tt, g) : NPAD;
+        hoff[tt] = src < NPAD ? M::rg_pos(src, cp) : ZPOS;
+      }
+      M::apply_rowgroup(A + CPL * lane, JYL + (g * RPG) * JYS, H, hoff, z[lane], dz[lane]);
+      for (int cc = 0; cc < CPL; ++cc)
+        for (int r = 0; r < RPG; ++r) {
+          const int grow = g * RPG + r, col = cp + C * cc;
+          if (active && grow < N && col < K) yout[N + grow * K + col] = dz[lane][r + RPG * cc];
+          else if (dz[lane][r + RPG * cc] != 0.0) return -2;   // padding must stay exactly zero
+        }
+    }
+    return 0;
   }
 }
 }

@@ -92,25 +92,44 @@ def test_kernel_variants_agree(gpu_models, golden, method, kw):
     assert np.array_equal(P[:4], g['P'])
     t_out = _from_zero(g['t'][g['idx']])
     res = {}
-    for variant in ('per_wave', 'row_lane'):
+    for variant in ('per_wave', 'row_lane', 'row_group'):
         S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method=method, variant=variant, **kw)
         assert m.last_info['status'].tolist() == [0] * 7
         res[variant] = (Y, S, m.last_info['n_steps'].copy())
         if method == 'dopri45':
             assert parity_err(Y[:4, 1:], g['Y']) <= 1.0 and parity_err(S[:4, 1:], g['S']) <= 1.0
     Ya, Sa, na = res['per_wave']
-    Yb, Sb, nb = res['row_lane']
-    assert np.allclose(Ya, Yb, rtol=1e-9, atol=1e-11) and np.allclose(Sa, Sb, rtol=1e-9, atol=1e-10)
-    assert np.all(np.abs(na - nb) <= 2)          # same controller, same step sequence up to rounding
+    for other in ('row_lane', 'row_group'):
+        Yb, Sb, nb = res[other]
+        assert np.allclose(Ya, Yb, rtol=1e-9, atol=1e-11) and np.allclose(Sa, Sb, rtol=1e-9, atol=1e-10)
+        assert np.all(np.abs(na - nb) <= 2)          # same controller, same step sequence up to rounding
     # failures stay per trajectory
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        Pbad = P.copy()
-        Pbad[2, 5] = np.nan
-        S = m.calc_jacobian_batch(Pbad, t_out, method=method, variant='row_lane', **kw)
-    assert m.last_info['status'][2] != 0 and np.all(np.isnan(S[2, -1]))
-    ok = [0, 1, 3, 4, 5, 6]
-    assert m.last_info['status'][ok].tolist() == [0] * 6 and np.array_equal(S[ok], Sb[ok])
+    for variant in ('row_lane', 'row_group'):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Pbad = P.copy()
+            Pbad[2, 5] = np.nan
+            S = m.calc_jacobian_batch(Pbad, t_out, method=method, variant=variant, **kw)
+        assert m.last_info['status'][2] != 0 and np.all(np.isnan(S[2, -1]))
+        ok = [0, 1, 3, 4, 5, 6]
+        assert m.last_info['status'][ok].tolist() == [0] * 6 and np.array_equal(S[ok], res[variant][1][ok])
+
+
+def test_row_group_kernel_on_two_state_model(gpu_models, golden):
+    """Michaelis-Menten (2 rows, 5 columns) splits into G = 2 groups of one row each: every J_y
+    term crosses a group boundary, i.e. goes through the LDS halo.  Same golden as the other
+    variants, plus initial conditions for S (the s0 path of the kernel)."""
+    m = gpu_models('michaelis_menten')
+    g = golden('mm_ref.npz')
+    for variant in ('per_wave', 'row_lane', 'row_group'):
+        S, Y = m.calc_jacobian_batch(g['P'], g['t'], return_states=True, variant=variant)
+        assert parity_err(Y, g['Y']) <= 1.0 and parity_err(S, g['S']) <= 1.0
+    rng = np.random.default_rng(2)
+    y0 = np.concatenate([[0.3, 0.1], rng.uniform(-1, 1, 10)])
+    t_out = np.linspace(0, 50, 6)
+    a = m.calc_jacobian_batch(g['P'], t_out, y0, variant='per_wave')
+    b = m.calc_jacobian_batch(g['P'], t_out, y0, variant='row_group')
+    assert np.allclose(a, b, rtol=1e-9, atol=1e-11) and np.array_equal(b[0, 0], y0[2:])
 
 
 def test_live_oracle_random_vectors(gpu_models, zoo):

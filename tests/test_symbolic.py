@@ -138,6 +138,12 @@ def test_hip_text_equals_python_and_c_on_host(name, tmp_path):
             out = np.zeros(n + n * k)
             fn(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp), p.ctypes.data_as(dp))
             assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
+        out = np.zeros(n + n * k)
+        rc_ = lib.h_sens_rhs_rowgroup(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp),
+                                      p.ctypes.data_as(dp))
+        assert rc_ == (-1 if name == 'simple' else 0)       # a single row cannot be split
+        if rc_ == 0:
+            assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
         ref_s = np.zeros(n)
         gm.model(y[:n].copy(), 0.0, ref_s, p)
         out = np.zeros(n)
@@ -163,3 +169,63 @@ def test_cascade_definition():
     assert P.shape == (16, 40) and np.allclose(np.exp(theta), P)
     theta2, _ = models_zoo.cascade_ensemble(16)
     assert np.array_equal(theta, theta2)   # seeded
+
+
+def test_rowgroup_form_of_an_irregular_network(tmp_path):
+    """Row-group emitter on a network whose rows do NOT line up across groups: mixed kinetic forms,
+    couplings at irregular distances (so most terms become LDS halo terms, several groups lack
+    terms others have), 11 rows over 13 columns.  The lane-by-lane emulation must still equal the
+    Python emitter's sensitivity RHS, and padding must stay exactly zero."""
+    import sympy
+    from collections import OrderedDict
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    from sysbio_modeling_amd.symbolic.emit import ModelSpec
+    from sysbio_modeling_amd.symbolic import emit_rowgroup
+    n = 11
+    xs = [sympy.Symbol('x%d' % i) for i in range(n)]
+    ks = [sympy.Symbol('k%d' % i) for i in range(n)]
+    d, K = sympy.Symbol('d'), sympy.Symbol('K')
+    eq = OrderedDict()
+    for i in range(n):
+        a, b = xs[(i * 3 + 1) % n], xs[(i + 5) % n]
+        if i % 3 == 0:
+            rhs = ks[i] * a / (K + a) - d * xs[i]
+        elif i % 3 == 1:
+            rhs = ks[i] * a * b - d * xs[i] * xs[i]
+        else:
+            rhs = ks[i] / (1 + b) - d * xs[i] + a
+        eq['x%d' % i] = rhs
+    spec = ModelSpec(name='irregular', variables=[str(x) for x in xs], params=[str(k) for k in ks] + ['d', 'K'],
+                     equations=eq)
+    gm = GeneratedModel(spec)
+    lay = emit_rowgroup.layout(spec, gm.derived)
+    assert lay is not None and lay['G'] >= 2 and len(lay['hsrc']) > 0
+    hdr = tmp_path / 'irregular.hpp'
+    hdr.write_text(gm.hip_source)
+    so = str(tmp_path / 'h_irregular.so')
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-DSBM_MODEL_HEADER="%s"' % hdr,
+                           os.path.join(HERE, 'support', 'host_model_harness.cpp'), '-o', so])
+    lib = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    k = gm.n_sens
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        y = rng.uniform(0.05, 2.0, n + n * k)
+        p = rng.uniform(0.05, 2.0, len(gm.param_order))
+        ref = np.zeros(n + n * k)
+        gm.sens_model(y, 0.0, ref, p)
+        for fn in (lib.h_sens_rhs_rowlane, lib.h_sens_rhs_rowgroup):
+            out = np.zeros(n + n * k)
+            rc_ = fn(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp), p.ctypes.data_as(dp))
+            assert rc_ in (0, None) or fn is lib.h_sens_rhs_rowlane
+            assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
+
+
+def test_rowgroup_plan():
+    from sysbio_modeling_amd.symbolic.emit_rowgroup import plan
+    assert plan(20, 40) == (3, 20, 2, 7)       # cascade20: 14 elements on 60 lanes instead of 20 on 40
+    assert plan(1, 2) is None                  # nothing to split
+    assert plan(70, 10) is None                # more rows than lanes: no row-lane form at all
+    assert plan(30, 64) is None                # every lane already carries a column
+    G, C, CPL, RPG = plan(30, 20)
+    assert G * C <= 64 and C * CPL >= 20 and G * RPG >= 30 and RPG * CPL <= 0.8 * 30
