@@ -70,18 +70,46 @@ __device__ __forceinline__ double sbm_bcast0(double v) {
 __device__ __forceinline__ float sbm_bcast0f(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
-__device__ __forceinline__ float sbm_wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return sbm_bcast0f(v);
+// Wave-wide reductions of the step controller, on DPP (data-parallel primitives: a VALU operand
+// taken from another lane of the same row of 16, no LDS crossbar round trip).  The __shfl_xor
+// butterflies they replace cost one ds_bpermute + s_waitcnt lgkmcnt(0) per level, ~20 dependent
+// LDS round trips per step over the controller's reductions -- at one wave per SIMD nothing
+// hides them.  Sequence as in rocPRIM's warp_reduce_dpp: two quad_perms and two row rotations leave
+// every lane of a row with the row's result, row_bcast:15 / :31 fold the four rows into lane 63.
+// Lanes of rows a row_mask disables read 0: fine for sums and for maxima of values >= 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float sbm_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
+__device__ __forceinline__ float sbm_lane63f(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// max over the wave of v >= 0 (NaN-free: callers map NaN to +inf first)
+__device__ __forceinline__ float sbm_wave_max(float v) {
+  v = fmaxf(v, sbm_dpp<0xb1, 0xf>(v));    // quad_perm:[1,0,3,2]
+  v = fmaxf(v, sbm_dpp<0x4e, 0xf>(v));    // quad_perm:[2,3,0,1]
+  v = fmaxf(v, sbm_dpp<0x124, 0xf>(v));   // row_ror:4
+  v = fmaxf(v, sbm_dpp<0x128, 0xf>(v));   // row_ror:8
+  v = fmaxf(v, sbm_dpp<0x142, 0xa>(v));   // row_bcast:15 -> rows 1, 3
+  v = fmaxf(v, sbm_dpp<0x143, 0xc>(v));   // row_bcast:31 -> rows 2, 3
+  return sbm_lane63f(v);
+}
+__device__ __forceinline__ float sbm_wave_sumf(float v) {
+  v += sbm_dpp<0xb1, 0xf>(v);
+  v += sbm_dpp<0x4e, 0xf>(v);
+  v += sbm_dpp<0x124, 0xf>(v);
+  v += sbm_dpp<0x128, 0xf>(v);
+  v += sbm_dpp<0x142, 0xa>(v);
+  v += sbm_dpp<0x143, 0xc>(v);
+  return sbm_lane63f(v);
+}
+// a failed evaluation (NaN) must surface as a failed step: +inf survives max and sum
+__device__ __forceinline__ float sbm_nan_to_inf(float v) { return (v != v) ? __builtin_inff() : v; }
 __device__ __forceinline__ double sbm_wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return sbm_bcast0(v);
 }
-// NaN-propagating: a NaN anywhere must surface as a failed step
-__device__ __forceinline__ float sbm_nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
 
 // ---------------------------------------------------------------------------
 // Dormand-Prince 5(4) tableau (Hairer, Norsett, Wanner, vol. I, table 5.2)
@@ -167,12 +195,8 @@ struct SensSystem {
   __device__ __forceinline__ float norm(const float (&colsum)[CPL], float /*xsum*/) const {
     float m = 0.f;
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) m = sbm_nanmax(m, colsum[c]);
-    // fmaxf drops NaNs: carry them explicitly
-    const float bad = (m != m) ? 1.f : 0.f;
-    const float mx = sbm_wave_max((m != m) ? 0.f : m);
-    const float anybad = sbm_wave_max(bad);
-    return anybad > 0.f ? __builtin_nanf("") : sqrtf(mx * (1.0f / NV));
+    for (int c = 0; c < CPL; ++c) m = fmaxf(m, sbm_nan_to_inf(colsum[c]));
+    return sqrtf(sbm_wave_max(m) * (1.0f / NV));   // +inf: the driver rejects the step
   }
   __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
   __device__ __forceinline__ int begin(double, const double (&)[CPL][NV]) const { return 0; }
@@ -644,16 +668,11 @@ struct RowLaneSystem {
   // per-wave kernel, with the state spread over the lanes
   __device__ __forceinline__ float norm(const float (&colsum)[1], float xsum) const {
     // lanes without a column / without a row carry no equation: they must not steer the controller
-    const float m = (lane < M::NK) ? colsum[0] : 0.f;
-    xsum = (lane < NV) ? xsum : 0.f;
-    const float bad = (m != m || xsum != xsum) ? 1.f : 0.f;
-    const float mx = sbm_wave_max((m != m) ? 0.f : m);
-    float xs = (xsum != xsum) ? 0.f : xsum;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) xs += __shfl_xor(xs, off, 64);
-    xs = sbm_bcast0f(xs);
-    const float anybad = sbm_wave_max(bad);
-    return anybad > 0.f ? __builtin_nanf("") : sqrtf(fmaxf(mx, xs) * (1.0f / NV));
+    const float m = (lane < M::NK) ? sbm_nan_to_inf(colsum[0]) : 0.f;
+    const float x = (lane < NV) ? sbm_nan_to_inf(xsum) : 0.f;
+    const float mx = sbm_wave_max(m);
+    const float xs = sbm_wave_sumf(x);
+    return sqrtf(fmaxf(mx, xs) * (1.0f / NV));   // +inf: the driver rejects the step
   }
   __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
 };
@@ -827,10 +846,9 @@ struct RowGroupSystem {
   // is spread over the G lanes cp, C + cp, ...
   __device__ __forceinline__ float norm(const float (&colsum)[NCS], float xsum) const {
     float m = 0.f;
-    float bad = 0.f;
 #pragma unroll
     for (int cc = 0; cc < NCS; ++cc) {
-      float v = active ? colsum[cc] : 0.f;
+      const float v = active ? sbm_nan_to_inf(colsum[cc]) : 0.f;
       float tot = v;
 #pragma unroll
       for (int gg = 1; gg < G; ++gg) {
@@ -839,19 +857,12 @@ struct RowGroupSystem {
         tot += __shfl(v, active ? src : lane, 64);
       }
       const bool has_col = active && (cp + C * cc < M::NK);
-      tot = has_col ? tot : 0.f;
-      bad = (tot != tot) ? 1.f : bad;
-      m = fmaxf(m, (tot != tot) ? 0.f : tot);
+      m = fmaxf(m, has_col ? tot : 0.f);
     }
-    xsum = (lane < M::NV) ? xsum : 0.f;
-    bad = (xsum != xsum) ? 1.f : bad;
+    const float x = (lane < M::NV) ? sbm_nan_to_inf(xsum) : 0.f;
     const float mx = sbm_wave_max(m);
-    float xs = (xsum != xsum) ? 0.f : xsum;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) xs += __shfl_xor(xs, off, 64);
-    xs = sbm_bcast0f(xs);
-    const float anybad = sbm_wave_max(bad);
-    return anybad > 0.f ? __builtin_nanf("") : sqrtf(fmaxf(mx, xs) * (1.0f / M::NV));
+    const float xs = sbm_wave_sumf(x);
+    return sqrtf(fmaxf(mx, xs) * (1.0f / M::NV));   // +inf: the driver rejects the step
   }
   __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
 };
