@@ -133,24 +133,35 @@ constexpr double E1 = 71.0 / 57600.0, E3 = -71.0 / 16695.0, E4 = 71.0 / 1920.0, 
 #define SBM_ALL(c, i)                       \
   _Pragma("unroll") for (int c = 0; c < CPL; ++c) \
   _Pragma("unroll") for (int i = 0; i < NVX; ++i)
-// the NV column rows / the NX extra elements separately: a stage first forms its extra elements
-// (the stage STATE in the row-lane kernel), hands them to Sys::begin() -- which starts the
-// evaluation of f / J_y / J_p -- and only then forms the column rows, so that the latency of that
-// evaluation is covered by independent arithmetic
+// the NV column rows / the NX extra elements (the stage STATE in the row-lane / row-group kernels)
 #define SBM_MAIN(c, i)                      \
   _Pragma("unroll") for (int c = 0; c < CPL; ++c) \
   _Pragma("unroll") for (int i = 0; i < NV; ++i)
 #define SBM_EXTRA(c, i)                     \
   _Pragma("unroll") for (int c = 0; c < CPL; ++c) \
   _Pragma("unroll") for (int i = NV; i < NVX; ++i)
-// stage = extras, begin, mains, finish
-#define SBM_STAGE(tt, expr, kout)           \
+// A stage runs in three phases:
+//   issue  : form the extra elements, make them visible (LDS) and START fetching the row operands;
+//   eval   : evaluate f / J_y / J_p of the lane's row, publish them; the extra elements of the
+//            stage derivative (kout) are known from here on;
+//   finish : form the column rows of the stage vector and their derivative.
+// The state path (issue, eval) does not depend on the column rows, so the drivers software-pipeline
+// it: stage s+1's issue is placed between eval and finish of stage s (SBM_STAGE_THEN's `next`),
+// and the LDS round trip of its operands is covered by the column work of stage s.
+#define SBM_ISSUE(tt, expr)                 \
   {                                         \
     SBM_EXTRA(c, i) zt[c][i] = (expr);      \
-    auto tok_ = sys.begin((tt), zt);        \
+    pend_ = sys.issue((tt), zt);            \
+  }
+#define SBM_STAGE_THEN(tt, expr, kout, next) \
+  {                                         \
+    auto tok_ = sys.eval(pend_, (tt));      \
+    sys.extra_out(tok_, kout);              \
+    next                                    \
     SBM_MAIN(c, i) zt[c][i] = (expr);       \
     sys.finish(tok_, (tt), zt, kout);       \
   }
+#define SBM_STAGE(tt, expr, kout) SBM_ISSUE(tt, expr) SBM_STAGE_THEN(tt, expr, kout, )
 
 // ---------------------------------------------------------------------------
 // "System" policies: what differs between the two mappings
@@ -199,7 +210,10 @@ struct SensSystem {
     return sqrtf(sbm_wave_max(m) * (1.0f / NV));   // +inf: the driver rejects the step
   }
   __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
-  __device__ __forceinline__ int begin(double, const double (&)[CPL][NV]) const { return 0; }
+  struct Pending {};
+  __device__ __forceinline__ Pending issue(double, const double (&)[CPL][NV]) const { return Pending{}; }
+  __device__ __forceinline__ int eval(const Pending&, double) const { return 0; }
+  __device__ __forceinline__ void extra_out(int, double (&)[CPL][NV]) const {}
   __device__ __forceinline__ void finish(int, double t, const double (&z)[CPL][NV], double (&dz)[CPL][NV]) const {
     rhs(t, z, dz);
   }
@@ -223,7 +237,10 @@ struct StateSystem {
     return sqrtf(colsum[0] * (1.0f / NV));
   }
   __device__ __forceinline__ double sum(double v) const { return v; }
-  __device__ __forceinline__ int begin(double, const double (&)[1][NV]) const { return 0; }
+  struct Pending {};
+  __device__ __forceinline__ Pending issue(double, const double (&)[1][NV]) const { return Pending{}; }
+  __device__ __forceinline__ int eval(const Pending&, double) const { return 0; }
+  __device__ __forceinline__ void extra_out(int, double (&)[1][NV]) const {}
   __device__ __forceinline__ void finish(int, double t, const double (&z)[1][NV], double (&dz)[1][NV]) const {
     rhs(t, z, dz);
   }
@@ -295,6 +312,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
 
   int n_try = 0;
   bool failed = false;
+  typename Sys::Pending pend_;
   for (int io = 0; io < n_t; ++io) {
     const double target = t_out[io];
     while (!failed && t < target) {
@@ -306,25 +324,33 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       if (t + 1.01 * hs >= target) { hs = target - t; last = true; }
 
       const double ha21 = hs * A21;
-      SBM_STAGE(t + C2 * hs, fma(ha21, k1[c][i], z[c][i]), k2)
       const double ha31 = hs * A31, ha32 = hs * A32;
-      SBM_STAGE(t + C3 * hs, fma(ha32, k2[c][i], fma(ha31, k1[c][i], z[c][i])), k3)
       const double ha41 = hs * A41, ha42 = hs * A42, ha43 = hs * A43;
-      SBM_STAGE(t + C4 * hs, fma(ha43, k3[c][i], fma(ha42, k2[c][i], fma(ha41, k1[c][i], z[c][i]))), k4)
       const double ha51 = hs * A51, ha52 = hs * A52, ha53 = hs * A53, ha54 = hs * A54;
-      SBM_STAGE(t + C5 * hs,
-                fma(ha54, k4[c][i], fma(ha53, k3[c][i], fma(ha52, k2[c][i], fma(ha51, k1[c][i], z[c][i])))), k5)
       const double ha61 = hs * A61, ha62 = hs * A62, ha63 = hs * A63, ha64 = hs * A64, ha65 = hs * A65;
-      SBM_STAGE(t + hs,
-                fma(ha65, k5[c][i],
-                    fma(ha64, k4[c][i], fma(ha63, k3[c][i], fma(ha62, k2[c][i], fma(ha61, k1[c][i], z[c][i]))))),
-                k6)
-      // 5th-order solution into zt; k2 is dead from here on and receives k7 = f(z_new) (FSAL)
       const double ha71 = hs * A71, ha73 = hs * A73, ha74 = hs * A74, ha75 = hs * A75, ha76 = hs * A76;
-      SBM_STAGE(t + hs,
-                fma(ha76, k6[c][i],
-                    fma(ha75, k5[c][i], fma(ha74, k4[c][i], fma(ha73, k3[c][i], fma(ha71, k1[c][i], z[c][i]))))),
-                k2)
+#define SBM_E2 fma(ha21, k1[c][i], z[c][i])
+#define SBM_E3 fma(ha32, k2[c][i], fma(ha31, k1[c][i], z[c][i]))
+#define SBM_E4 fma(ha43, k3[c][i], fma(ha42, k2[c][i], fma(ha41, k1[c][i], z[c][i])))
+#define SBM_E5 fma(ha54, k4[c][i], fma(ha53, k3[c][i], fma(ha52, k2[c][i], fma(ha51, k1[c][i], z[c][i]))))
+#define SBM_E6 \
+  fma(ha65, k5[c][i], fma(ha64, k4[c][i], fma(ha63, k3[c][i], fma(ha62, k2[c][i], fma(ha61, k1[c][i], z[c][i])))))
+#define SBM_E7 \
+  fma(ha76, k6[c][i], fma(ha75, k5[c][i], fma(ha74, k4[c][i], fma(ha73, k3[c][i], fma(ha71, k1[c][i], z[c][i])))))
+      SBM_ISSUE(t + C2 * hs, SBM_E2)
+      SBM_STAGE_THEN(t + C2 * hs, SBM_E2, k2, SBM_ISSUE(t + C3 * hs, SBM_E3))
+      SBM_STAGE_THEN(t + C3 * hs, SBM_E3, k3, SBM_ISSUE(t + C4 * hs, SBM_E4))
+      SBM_STAGE_THEN(t + C4 * hs, SBM_E4, k4, SBM_ISSUE(t + C5 * hs, SBM_E5))
+      SBM_STAGE_THEN(t + C5 * hs, SBM_E5, k5, SBM_ISSUE(t + hs, SBM_E6))
+      SBM_STAGE_THEN(t + hs, SBM_E6, k6, SBM_ISSUE(t + hs, SBM_E7))
+      // 5th-order solution into zt; k2 is dead from here on and receives k7 = f(z_new) (FSAL)
+      SBM_STAGE_THEN(t + hs, SBM_E7, k2, )
+#undef SBM_E2
+#undef SBM_E3
+#undef SBM_E4
+#undef SBM_E5
+#undef SBM_E6
+#undef SBM_E7
 
       // embedded error estimate; ratios and norm in f32 (they only steer the controller)
       const double he1 = hs * E1, he3 = hs * E3, he4 = hs * E4, he5 = hs * E5, he6 = hs * E6, he7 = hs * E7;
@@ -399,6 +425,7 @@ __device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::C
   constexpr int CPL = Sys::CPL;
   double k[CPL][NVX], acc[CPL][NVX], zt[CPL][NVX];
   SBM_ALL(c, i) { k[c][i] = 0.0; acc[c][i] = 0.0; zt[c][i] = 0.0; }
+  typename Sys::Pending pend_;
   SbmTrajOut out{SBM_OK, 0, 0};
   const double h0 = o.h0;
   const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000000;
@@ -611,23 +638,27 @@ struct RowLaneSystem {
     double f;                  // derivative of this lane's state component
     double jy[M::RL_MAXJY];    // J_y entries of this lane's row (read by the other lanes via v_readlane)
   };
-  // phase 1: publish this lane's stage state, evaluate the lane's row, publish its J_p entries and
-  // fetch this lane's column of A.  Called BEFORE the column rows of the stage are formed so that
-  // the LDS round trips and the dependent arithmetic of the row are covered by that work.
-  __device__ __forceinline__ Token begin(double t, const double (&z)[1][NVX]) const {
-    Token k;
+  struct Pending { double ys[M::RL_MAXYS]; };   // the row's state operands, in flight from LDS
+  // issue: publish this lane's stage state and start fetching the operands of the lane's row
+  __device__ __forceinline__ Pending issue(double /*t*/, const double (&z)[1][NVX]) const {
+    Pending p;
     sh->Y[lane] = z[0][NV];
     lds_order();
-    double ys[M::RL_MAXYS];
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXYS; ++s) ys[s] = sh->Y[yidx[s]];
+    for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[s] = sh->Y[yidx[s]];
+    lds_order();
+    return p;
+  }
+  // eval: evaluate the lane's row and publish its J_p entries
+  __device__ __forceinline__ Token eval(const Pending& p, double t) const {
+    Token k;
     double jp[M::RL_MAXJP];
     k.f = 0.0;
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJY; ++s) k.jy[s] = 0.0;
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
-    M::class_dispatch(cls, t, ys, ps, k.f, k.jy, jp);
+    M::class_dispatch(cls, t, p.ys, ps, k.f, k.jy, jp);
     lds_order();
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
@@ -658,10 +689,11 @@ struct RowLaneSystem {
 #endif
 #pragma unroll
     for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
-    dz[0][NV] = k.f;
   }
+  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][NVX]) const { dz[0][NV] = k.f; }
   __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
-    const Token k = begin(t, z);
+    const Token k = eval(issue(t, z), t);
+    extra_out(k, dz);
     finish(k, t, z, dz);
   }
   // max( RMS of the state error, max over columns of the column RMS ): the same test as the
@@ -778,7 +810,10 @@ struct SbmRowGroupShared {
   alignas(16) double H[M::RG_RPG * LS + 4];        // published rows of the stage vector (+ zero slot)
 };
 
-template <class M>
+// EARLY: fetch the lane's A / J_y operands right after the row lanes published them (eval) instead of
+// in finish, so that the column rows of the stage vector are formed while they are in flight.  Costs
+// 2*(NV + RPG*JYS) more live VGPRs: pays for RK4 (18.0 vs 19.4 ms), spills for DOPRI45 (20.7 vs 7.5 ms).
+template <class M, bool EARLY>
 struct RowGroupSystem {
   static constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG;
   static constexpr int NV = M::RG_RPG * M::RG_CPL;   // elements of S this lane integrates
@@ -802,27 +837,39 @@ struct RowGroupSystem {
 
   __device__ __forceinline__ static void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 
-  struct Token { double f; };
-  __device__ __forceinline__ Token begin(double t, const double (&z)[1][NVX]) const {
-    Token k;
+  struct Token {
+    double f;
+    double acol[EARLY ? NV : 1], coef[EARLY ? RPG * M::RG_JYS : 1];
+  };
+  struct Pending { double ys[M::RL_MAXYS]; };
+  __device__ __forceinline__ Pending issue(double /*t*/, const double (&z)[1][NVX]) const {
+    Pending p;
     sh->Y[lane] = z[0][NV];
     lds_order();
-    double ys[M::RL_MAXYS];
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXYS; ++s) ys[s] = sh->Y[yidx[s]];
+    for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[s] = sh->Y[yidx[s]];
+    lds_order();
+    return p;
+  }
+  __device__ __forceinline__ Token eval(const Pending& p, double t) const {
+    Token k;
     double jy[M::RL_MAXJY], jp[M::RL_MAXJP];
     k.f = 0.0;
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
-    M::class_dispatch(cls, t, ys, ps, k.f, jy, jp);
+    M::class_dispatch(cls, t, p.ys, ps, k.f, jy, jp);
     lds_order();
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJY; ++s) sh->JYL[jypos[s]] = jy[s];
     lds_order();
+    if constexpr (EARLY) {
+      M::load_rowgroup(a_lane, jy_lane, k.acol, k.coef);
+      lds_order();
+    }
     return k;
   }
   __device__ __forceinline__ void finish(const Token& k, double /*t*/, const double (&z)[1][NVX],
@@ -832,14 +879,21 @@ struct RowGroupSystem {
     for (int i = 0; i < NV; ++i) zc[i] = z[0][i];
     M::publish_rowgroup(h_lane, zc);
     lds_order();
-    M::apply_rowgroup(a_lane, jy_lane, sh->H, hoff, zc, dc);
+    if constexpr (EARLY) {
+      M::apply_rowgroup(k.acol, k.coef, sh->H, hoff, zc, dc);
+    } else {
+      double acol[NV], coef[RPG * M::RG_JYS];
+      M::load_rowgroup(a_lane, jy_lane, acol, coef);
+      M::apply_rowgroup(acol, coef, sh->H, hoff, zc, dc);
+    }
     lds_order();
 #pragma unroll
     for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
-    dz[0][NV] = k.f;
   }
+  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][NVX]) const { dz[0][NV] = k.f; }
   __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
-    const Token k = begin(t, z);
+    const Token k = eval(issue(t, z), t);
+    extra_out(k, dz);
     finish(k, t, z, dz);
   }
   // max( RMS of the state error, max over columns of the column RMS ); a column's sum of squares
@@ -869,7 +923,7 @@ struct RowGroupSystem {
 
 template <class M, int METHOD>
 __global__ void __launch_bounds__(64) sbm_sens_rowgroup_kernel(sbm_kernel_args a) {
-  using Sys = RowGroupSystem<M>;
+  using Sys = RowGroupSystem<M, METHOD == SBM_RK4_FIXED>;
   using Sh = SbmRowGroupShared<M>;
   constexpr int MNV = M::NV, NK = M::NK;
   constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG, CPL = M::RG_CPL;

@@ -133,8 +133,9 @@ def emit_members(spec, d, lay):
                 "  __device__ __forceinline__ static int rg_hsrc(int, int) { return 0; }",
                 "  __device__ __forceinline__ static int rg_pos(int row, int col) { return row * 64 + col; }",
                 "  template <int NZ> __device__ __forceinline__ static void publish_rowgroup(double*, const double (&)[NZ]) {}",
-                "  template <int NZ> __device__ __forceinline__ static void apply_rowgroup(const double*, const double*, const double*,",
-                "      const int (&)[1], const double (&)[NZ], double (&)[NZ]) {}"]
+                "  __device__ __forceinline__ static void load_rowgroup(const double*, const double*, double (&)[NV], double (&)[NV]) {}",
+                "  template <int NZ> __device__ __forceinline__ static void apply_rowgroup(const double (&)[NV], const double (&)[NV],",
+                "      const double*, const int (&)[1], const double (&)[NZ], double (&)[NZ]) {}"]
     G, C, CPL, RPG, jys, LS = lay['G'], lay['C'], lay['CPL'], lay['RPG'], lay['jys'], lay['LS']
     nh = len(lay['hsrc'])
     L = ["  // ---- row-group form (sbm_sens_rowgroup_kernel): lane (g, c') = rows [g*RPG, (g+1)*RPG) of",
@@ -157,25 +158,37 @@ def emit_members(spec, d, lay):
         for cc in range(CPL):
             L.append("    h_lane[%d] = z[%d];" % (r * LS + cc, r + RPG * cc))
     L += ["  }",
-          "  // dz = J_y z + A for the lane's rows of its columns.  a_lane = A + CPL*lane, jy_lane = &JYL[g*RPG][0]",
-          "  // (layout JYL[row][RG_JYS]), h_all = H, hoff[t] = rg_pos(rg_hsrc(t, g), c') or the zero slot RPG*LS.",
+          "  // operands of apply_rowgroup from LDS: a_lane = A + CPL*lane, jy_lane = &JYL[g*RPG][0] (layout",
+          "  // JYL[row][RG_JYS]); acol[r + RPG*cc] = this lane's J_p entries, coef[r*RG_JYS + k] = J_y coefficients",
+          "  __device__ __forceinline__ static void load_rowgroup(const double* a_lane, const double* jy_lane,",
+          "                                                       double (&acol)[%d], double (&coef)[%d]) {" % (RPG * CPL, RPG * jys)]
+    for r in range(RPG):
+        for k in range(jys):
+            L.append("    coef[%d] = jy_lane[%d];" % (r * jys + k, r * jys + k))
+    for r in range(RPG):
+        for cc in range(CPL):
+            L.append("    acol[%d] = a_lane[%d];" % (r + RPG * cc, r * LS + cc))
+    L += ["  }",
+          "  // dz = J_y z + A for the lane's rows of its columns; h_all = H, hoff[t] = rg_pos(rg_hsrc(t, g), c')",
+          "  // or the zero slot RPG*LS (term absent in this lane's group).",
           "  template <int NZ>",
-          "  __device__ __forceinline__ static void apply_rowgroup(const double* a_lane, const double* jy_lane,",
+          "  __device__ __forceinline__ static void apply_rowgroup(const double (&acol)[%d], const double (&coef)[%d]," % (RPG * CPL, RPG * jys),
           "                                                        const double* h_all, const int (&hoff)[%d]," % max(nh, 1),
           "                                                        const double (&z)[NZ], double (&dz)[NZ]) {",
-          "    (void)jy_lane; (void)h_all; (void)hoff;"]
+          "    (void)h_all; (void)hoff;"]
     for r in range(RPG):
         for k, t in enumerate(lay['terms'][r]):
-            L.append("    const double c%d_%d = jy_lane[%d];" % (r, k, r * jys + k))
             if t['halo'] is not None:
                 for cc in range(CPL):
                     L.append("    const double h%d_%d_%d = h_all[hoff[%d] + %d];" % (r, k, cc, t['halo'], cc))
+    # rows without halo terms first: their operands arrive before the halo reads issued last
+    order = sorted(range(RPG), key=lambda r: any(t['halo'] is not None for t in lay['terms'][r]))
     for cc in range(CPL):
-        for r in range(RPG):
-            expr = "a_lane[%d]" % (r * LS + cc)
+        for r in order:
+            expr = "acol[%d]" % (r + RPG * cc)
             for k, t in enumerate(lay['terms'][r]):
                 src = ("z[%d]" % (t['own'] + RPG * cc)) if t['own'] is not None else ("h%d_%d_%d" % (r, k, cc))
-                expr = "fma(c%d_%d, %s, %s)" % (r, k, src, expr)
+                expr = "fma(coef[%d], %s, %s)" % (r * jys + k, src, expr)
             L.append("    dz[%d] = %s;" % (r + RPG * cc, expr))
     L += ["  }"]
     return L

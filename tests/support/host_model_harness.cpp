@@ -146,7 +146,9 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
         const int src = (M::RG_NHALO > 0 && active) ? M::rg_hsrc(tt, g) : NPAD;
         hoff[tt] = src < NPAD ? M::rg_pos(src, cp) : ZPOS;
       }
-      M::apply_rowgroup(A + CPL * lane, JYL + (g * RPG) * JYS, H, hoff, z[lane], dz[lane]);
+      double acol[NE], coef[RPG * JYS];
+      M::load_rowgroup(A + CPL * lane, JYL + (g * RPG) * JYS, acol, coef);
+      M::apply_rowgroup(acol, coef, H, hoff, z[lane], dz[lane]);
       for (int cc = 0; cc < CPL; ++cc)
         for (int r = 0; r < RPG; ++r) {
           const int grow = g * RPG + r, col = cp + C * cc;
