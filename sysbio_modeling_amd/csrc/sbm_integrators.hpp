@@ -659,6 +659,7 @@ struct RowLaneSystem {
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
     M::class_dispatch(cls, t, p.ys, ps, k.f, k.jy, jp);
+    k.f = cls >= 0 ? k.f : 0.0;   // lanes without a row come out of the select chain with the last class's value
     lds_order();
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
@@ -860,6 +861,7 @@ struct RowGroupSystem {
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
     M::class_dispatch(cls, t, p.ys, ps, k.f, jy, jp);
+    k.f = cls >= 0 ? k.f : 0.0;   // lanes without a row come out of the select chain with the last class's value
     lds_order();
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];

@@ -117,18 +117,39 @@ def emit_rowlane_members(spec, d, meta, make_printer):
     # Branch-free: every class body is evaluated on every lane (a divergent if/else chain would
     # execute all bodies one after the other anyway) and the lane keeps the results of ITS class
     # through by-value selects.  No per-lane control flow is left in the kernel, which matters
-    # because other lanes read these registers with v_readlane.
+    # because other lanes read these registers with v_readlane.  The LAST class is the default of
+    # the select chain (n-1 selects per output instead of n): lanes without a row (cls = -1) end up
+    # with its values, which the kernels discard (spare LDS slots) or zero (f).
+    bodies = []
     for ci, c in enumerate(classes):
         L.append("    // class %d: rows %s" % (ci, ", ".join(str(r) for r in c['rows'])))
         repl, red = cse(list(c['canon']), symbols=sympy.numbered_symbols('c%d_x' % ci), optimizations='basic')
         for sym, e in repl:
             L.append("    const double %s = %s;" % (sym, pr.doprint(e)))
+        bodies.append([pr.doprint(e) for e in red])
+    last = len(classes) - 1
+    for ci in range(last):
         L.append("    const bool is%d = (cls == %d);" % (ci, ci))
-        L.append("    f = SBM_SEL(is%d, %s, f);" % (ci, pr.doprint(red[0])))
-        for k in range(c['n_jy']):
-            L.append("    jy[%d] = SBM_SEL(is%d, %s, jy[%d]);" % (k, ci, pr.doprint(red[1 + k]), k))
-        for k in range(c['n_jp']):
-            L.append("    jp[%d] = SBM_SEL(is%d, %s, jp[%d]);" % (k, ci, pr.doprint(red[1 + c['n_jy'] + k]), k))
+
+    def chain(kind, k):
+        """value of output (kind, k): the last class's expression (or 0), overridden class by class"""
+        def of(ci):
+            c = classes[ci]
+            if kind == 'f':
+                return bodies[ci][0]
+            if kind == 'jy':
+                return bodies[ci][1 + k] if k < c['n_jy'] else "0.0"
+            return bodies[ci][1 + c['n_jy'] + k] if k < c['n_jp'] else "0.0"
+        expr = of(last)
+        for ci in range(last - 1, -1, -1):
+            expr = "SBM_SEL(is%d, %s, %s)" % (ci, of(ci), expr)
+        return expr
+
+    L.append("    f = %s;" % chain('f', 0))
+    for k in range(meta['max_jy']):
+        L.append("    jy[%d] = %s;" % (k, chain('jy', k)))
+    for k in range(meta['max_jp']):
+        L.append("    jp[%d] = %s;" % (k, chain('jp', k)))
     # which (row lane, slot) holds J_y non-zero e; entries that depend on parameters only are
     # STATIC: the same for every stage of every step, broadcast once per kernel (rl_static)
     where = {}
