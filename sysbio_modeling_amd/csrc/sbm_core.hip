@@ -51,12 +51,7 @@ struct sbm_ctx {
   bool own_stream;
 };
 
-struct sbm_model {
-  sbm_ctx* ctx;
-  void* dl;
-  sbm_plugin_info_t info;
-  sbm_plugin_launch_fn launch;
-};
+struct sbm_model;
 
 template <class T>
 struct DevBuf {
@@ -76,6 +71,17 @@ struct DevBuf {
     p = nullptr;
     n = 0;
   }
+};
+
+struct sbm_model {
+  sbm_ctx* ctx;
+  void* dl;
+  sbm_plugin_info_t info;
+  sbm_plugin_launch_fn launch;
+  // launch order of the sensitivity kernels (launch_sens): trajectories sorted by the cost of the
+  // previous launch of the same size, most expensive first
+  DevBuf<int32_t> order, cost_steps, cost_rej;
+  int order_T = 0;   // number of trajectories `order` is a permutation of (0: none yet)
 };
 
 struct sbm_project {
@@ -163,6 +169,8 @@ extern "C" int sbm_model_load(sbm_ctx* ctx, const char* path, sbm_model** out) {
 extern "C" int sbm_model_unload(sbm_model* m) {
   if (!m) return 0;
   // the plugin's code object stays registered with the HIP runtime: do not dlclose
+  (void)hipSetDevice(m->ctx->device);
+  m->order.release(); m->cost_steps.release(); m->cost_rej.release();
   delete m;
   return 0;
 }
@@ -204,6 +212,68 @@ static int launch(sbm_model* m, int kind, const sbm_kernel_args& a, const char* 
   return 0;
 }
 
+// ---- launch order of the sensitivity kernels ---------------------------------------------------
+// An adaptive integrator takes a different number of steps for every parameter vector (configs[2]:
+// 445 ... 574, mean 485).  One trajectory occupies one SIMD for its whole life, the hardware hands
+// out workgroups in index order, and the kernel ends when the last trajectory does: in index order
+// the chip idles for 5.8 % of the launch at 4 trajectories per SIMD (scripts/dev_balance.py).  A
+// fitting loop integrates nearly the same ensemble again and again, so the step counts of the
+// previous launch predict the next one: sort by them, longest first (LPT), 1.9 %.  The order only
+// changes which workgroup integrates which trajectory, never a result.
+__global__ void __launch_bounds__(1024) k_order(const int32_t* __restrict__ steps, const int32_t* __restrict__ rej, int T,
+                                                int32_t* __restrict__ order) {
+  constexpr int NB = 2048;
+  __shared__ int hist[NB];
+  __shared__ int smax;
+  const int tid = threadIdx.x;
+  for (int b = tid; b < NB; b += blockDim.x) hist[b] = 0;
+  if (tid == 0) smax = 1;
+  __syncthreads();
+  int mx = 1;
+  for (int i = tid; i < T; i += blockDim.x) mx = max(mx, steps[i] + rej[i]);
+  atomicMax(&smax, mx);
+  __syncthreads();
+  const double scale = (double)(NB - 1) / (double)smax;
+  // bin 0 = most expensive
+  for (int i = tid; i < T; i += blockDim.x) {
+    const int c = max(0, steps[i] + rej[i]);
+    atomicAdd(&hist[NB - 1 - (int)(c * scale)], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 0; b < NB; ++b) { const int h = hist[b]; hist[b] = run; run += h; }
+  }
+  __syncthreads();
+  for (int i = tid; i < T; i += blockDim.x) {
+    const int c = max(0, steps[i] + rej[i]);
+    order[atomicAdd(&hist[NB - 1 - (int)(c * scale)], 1)] = i;
+  }
+}
+
+static int launch_sens(sbm_model* m, sbm_kernel_args a, const char* who) {
+  SBM_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->stream;
+  const int T = a.n_traj;
+  // the order is only worth its bookkeeping when trajectories queue behind each other
+  const bool use = T >= 2048;
+  if (use) {
+    if (m->order.reserve(T) || m->cost_steps.reserve(T) || m->cost_rej.reserve(T))
+      return sbm_fail(SBM_E_HIP, "%s: out of device memory", who);
+    if (m->order_T == T) a.order = m->order.p;
+    if (!a.n_steps) a.n_steps = m->cost_steps.p;
+    if (!a.n_reject) a.n_reject = m->cost_rej.p;
+  }
+  int e = m->launch(SBM_KIND_SENS, &a, (void*)s);
+  if (e != 0) return sbm_fail(SBM_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString((hipError_t)e));
+  if (use) {
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s, a.n_steps, a.n_reject, T, m->order.p);
+    SBM_HIP(hipGetLastError());
+    m->order_T = T;
+  }
+  return 0;
+}
+
 extern "C" int sbm_simulate_batch(sbm_model* m, const double* P, int32_t V, const double* t_out, int32_t n_t,
                                   const double* y0, const sbm_integrator_opts* opts, double* Y, int32_t* status,
                                   int32_t* n_steps, int32_t* n_reject) {
@@ -235,7 +305,7 @@ extern "C" int sbm_sens_batch(sbm_model* m, const double* P, int32_t V, const do
   a.Y = Y; a.S = S;
   a.status = status; a.n_steps = n_steps; a.n_reject = n_reject;
   a.n_traj = V; a.n_t = n_t; a.opts = *opts;
-  return launch(m, SBM_KIND_SENS, a, "sbm_sens_batch");
+  return launch_sens(m, a, "sbm_sens_batch");
 }
 
 // ---- host-pointer variants -------------------------------------------------
@@ -812,7 +882,7 @@ static int project_run(sbm_project* p, const double* Theta, int V, const sbm_int
   a.Y = p->Y.p; a.S = sens ? p->S.p : nullptr;
   a.status = p->traj_status.p; a.n_steps = p->traj_steps.p; a.n_reject = p->traj_rej.p;
   a.n_traj = (int32_t)T; a.n_t = nt; a.opts = *opts;
-  rc = launch(m, sens ? SBM_KIND_SENS : SBM_KIND_STATE, a, who);
+  rc = sens ? launch_sens(m, a, who) : launch(m, SBM_KIND_STATE, a, who);
   if (rc) return rc;
 
   AssembleArgs g;

@@ -481,9 +481,9 @@ __global__ void __launch_bounds__(64) sbm_sens_kernel(sbm_kernel_args a) {
   constexpr int NV = Sys::NV;
   constexpr int CPL = Sys::CPL;
   constexpr int NK = M::NK;
-  const int traj = blockIdx.x;  // wave-uniform
+  if ((int)blockIdx.x >= a.n_traj) return;
+  const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;  // wave-uniform
   const int lane = threadIdx.x;
-  if (traj >= a.n_traj) return;
 
   Sys sys{a.P + (size_t)traj * M::NP, lane};
   const int goff = a.grid_off ? a.grid_off[traj] : 0;
@@ -718,9 +718,9 @@ __global__ void __launch_bounds__(64) sbm_sens_rowlane_kernel(sbm_kernel_args a)
   constexpr int NK = M::NK;
   static_assert(NV <= 64 && NK <= 64, "row-lane kernel: one row and one column per lane");
   __shared__ SbmRowLaneShared<M> sh;
-  const int traj = blockIdx.x;
+  if ((int)blockIdx.x >= a.n_traj) return;
+  const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int lane = threadIdx.x;
-  if (traj >= a.n_traj) return;
 
   for (int i = lane; i < NV * 64 + 2; i += 64) sh.A[i] = 0.0;
   for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
@@ -932,9 +932,9 @@ __global__ void __launch_bounds__(64) sbm_sens_rowgroup_kernel(sbm_kernel_args a
   constexpr int NE = Sys::NV, NVX = Sys::NVX, NPAD = Sh::NPAD;
   static_assert(MNV <= 64 && G * C <= 64 && C * CPL <= 64 && C * CPL >= NK && NPAD >= MNV, "row-group layout");
   __shared__ Sh sh;
-  const int traj = blockIdx.x;
+  if ((int)blockIdx.x >= a.n_traj) return;
+  const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int lane = threadIdx.x;
-  if (traj >= a.n_traj) return;
 
   constexpr int NROWS = Sh::NROWS;
   constexpr int LS = Sh::LS;

@@ -7,7 +7,7 @@
 #include <stdint.h>
 #include "../../include/sbm.h"
 
-#define SBM_PLUGIN_ABI 1
+#define SBM_PLUGIN_ABI 2
 
 typedef struct sbm_plugin_info_t {
   int32_t abi;
@@ -30,6 +30,8 @@ typedef struct sbm_kernel_args {
   int32_t* status;          /* [n_traj] nullable */
   int32_t* n_steps;         /* [n_traj] nullable */
   int32_t* n_reject;        /* [n_traj] nullable */
+  const int32_t* order;     /* [n_traj] permutation or NULL: workgroup b integrates trajectory
+                             * order[b] (sens kernels; longest first, see sbm_core.hip)    */
   int32_t n_traj;
   int32_t n_t;              /* rows allocated per trajectory in Y / S                     */
   sbm_integrator_opts opts;

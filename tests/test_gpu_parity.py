@@ -631,3 +631,24 @@ def test_project_other_losses_vs_oracle(gpu_models, zoo, loss, compat):
             pb = Project(gpu_models('michaelis_menten'), bad, {}, {'S': ('direct', 0)}, loss_function=cls)
         with pytest.raises(ValueError, match="smaller or equal to zero"):
             pb.residuals(np.log(p_true))
+
+
+def test_launch_order_does_not_change_results(gpu_models):
+    """From 2048 trajectories on, the library launches the sensitivity kernel longest-trajectory-first,
+    using the step counts of the previous launch of the same size (sbm_core.hip::launch_sens).  The
+    first call runs in index order, the second sorted, the third sorted by the second's counts on
+    DIFFERENT parameters: every output must be bitwise what index order gives."""
+    from sysbio_modeling_amd import models_zoo
+    m = gpu_models('cascade20')
+    _, P = models_zoo.cascade_ensemble(2048)
+    t_out = _from_zero(np.linspace(6.25, 100.0, 4))
+    S1, Y1 = m.calc_jacobian_batch(P, t_out, return_states=True)
+    n1 = m.last_info['n_steps'].copy()
+    S2, Y2 = m.calc_jacobian_batch(P, t_out, return_states=True)
+    assert np.array_equal(S1, S2) and np.array_equal(Y1, Y2) and np.array_equal(n1, m.last_info['n_steps'])
+    assert n1.min() < n1.max()                      # there is something to sort
+    P3 = P[::-1].copy()                             # stale order: worst case for the predictor
+    S3 = m.calc_jacobian_batch(P3, t_out)
+    assert np.array_equal(S3, S1[::-1])
+    S4 = m.calc_jacobian_batch(P3[:100], t_out)     # small batches bypass the ordering
+    assert np.array_equal(S4, S3[:100])
