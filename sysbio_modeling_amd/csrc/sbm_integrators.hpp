@@ -148,20 +148,22 @@ constexpr double E1 = 71.0 / 57600.0, E3 = -71.0 / 16695.0, E4 = 71.0 / 1920.0, 
 // The state path (issue, eval) does not depend on the column rows, so the drivers software-pipeline
 // it: stage s+1's issue is placed between eval and finish of stage s (SBM_STAGE_THEN's `next`),
 // and the LDS round trip of its operands is covered by the column work of stage s.
-#define SBM_ISSUE(tt, expr)                 \
+// `stmt` forms element [c][i] of the stage vector zt (and may update running sums next to it); it is
+// run once for the extra elements (issue) and once for the column rows (finish side).
+#define SBM_ISSUE(tt, stmt)                 \
   {                                         \
-    SBM_EXTRA(c, i) zt[c][i] = (expr);      \
+    SBM_EXTRA(c, i) { stmt }                \
     pend_ = sys.issue((tt), zt);            \
   }
-#define SBM_STAGE_THEN(tt, expr, kout, next) \
+#define SBM_STAGE_THEN(tt, stmt, kout, next) \
   {                                         \
     auto tok_ = sys.eval(pend_, (tt));      \
     sys.extra_out(tok_, kout);              \
     next                                    \
-    SBM_MAIN(c, i) zt[c][i] = (expr);       \
+    SBM_MAIN(c, i) { stmt }                 \
     sys.finish(tok_, (tt), zt, kout);       \
   }
-#define SBM_STAGE(tt, expr, kout) SBM_ISSUE(tt, expr) SBM_STAGE_THEN(tt, expr, kout, )
+#define SBM_STAGE(tt, stmt, kout) SBM_ISSUE(tt, stmt) SBM_STAGE_THEN(tt, stmt, kout, )
 
 // ---------------------------------------------------------------------------
 // "System" policies: what differs between the two mappings
@@ -329,31 +331,48 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       const double ha51 = hs * A51, ha52 = hs * A52, ha53 = hs * A53, ha54 = hs * A54;
       const double ha61 = hs * A61, ha62 = hs * A62, ha63 = hs * A63, ha64 = hs * A64, ha65 = hs * A65;
       const double ha71 = hs * A71, ha73 = hs * A73, ha74 = hs * A74, ha75 = hs * A75, ha76 = hs * A76;
-#define SBM_E2 fma(ha21, k1[c][i], z[c][i])
-#define SBM_E3 fma(ha32, k2[c][i], fma(ha31, k1[c][i], z[c][i]))
-#define SBM_E4 fma(ha43, k3[c][i], fma(ha42, k2[c][i], fma(ha41, k1[c][i], z[c][i])))
-#define SBM_E5 fma(ha54, k4[c][i], fma(ha53, k3[c][i], fma(ha52, k2[c][i], fma(ha51, k1[c][i], z[c][i]))))
-#define SBM_E6 \
-  fma(ha65, k5[c][i], fma(ha64, k4[c][i], fma(ha63, k3[c][i], fma(ha62, k2[c][i], fma(ha61, k1[c][i], z[c][i])))))
-#define SBM_E7 \
-  fma(ha76, k6[c][i], fma(ha75, k5[c][i], fma(ha74, k4[c][i], fma(ha73, k3[c][i], fma(ha71, k1[c][i], z[c][i])))))
-      SBM_ISSUE(t + C2 * hs, SBM_E2)
-      SBM_STAGE_THEN(t + C2 * hs, SBM_E2, k2, SBM_ISSUE(t + C3 * hs, SBM_E3))
-      SBM_STAGE_THEN(t + C3 * hs, SBM_E3, k3, SBM_ISSUE(t + C4 * hs, SBM_E4))
-      SBM_STAGE_THEN(t + C4 * hs, SBM_E4, k4, SBM_ISSUE(t + C5 * hs, SBM_E5))
-      SBM_STAGE_THEN(t + C5 * hs, SBM_E5, k5, SBM_ISSUE(t + hs, SBM_E6))
-      SBM_STAGE_THEN(t + hs, SBM_E6, k6, SBM_ISSUE(t + hs, SBM_E7))
-      // 5th-order solution into zt; k2 is dead from here on and receives k7 = f(z_new) (FSAL)
-      SBM_STAGE_THEN(t + hs, SBM_E7, k2, )
-#undef SBM_E2
-#undef SBM_E3
-#undef SBM_E4
-#undef SBM_E5
-#undef SBM_E6
-#undef SBM_E7
-
-      // embedded error estimate; ratios and norm in f32 (they only steer the controller)
       const double he1 = hs * E1, he3 = hs * E3, he4 = hs * E4, he5 = hs * E5, he6 = hs * E6, he7 = hs * E7;
+      // Stages 2-4 combine the stored derivatives.  From stage 5 on every remaining linear
+      // combination (the inputs of stages 6 and 7 and the error estimate) is carried as a RUNNING SUM
+      // instead: when the input of stage 5 is formed, k2 / k3 / k4 are read one last time and their
+      // registers take over the partial sums Y6 / Y7 / E.  Same number of FMAs, but each derivative is
+      // read once instead of up to four times, and the live set peaks at 7 stage vectors instead of 8
+      // (z, k1, zt, Y6, Y7, E, k5), falling to 5 by stage 7 -- it is the v_accvgpr traffic of the
+      // overflowing register file that this saves.
+#define SBM_S2 zt[c][i] = fma(ha21, k1[c][i], z[c][i]);
+#define SBM_S3 zt[c][i] = fma(ha32, k2[c][i], fma(ha31, k1[c][i], z[c][i]));
+#define SBM_S4 zt[c][i] = fma(ha43, k3[c][i], fma(ha42, k2[c][i], fma(ha41, k1[c][i], z[c][i])));
+#define SBM_S5                                                                              \
+  const double a1_ = k1[c][i], a2_ = k2[c][i], a3_ = k3[c][i], a4_ = k4[c][i], zi_ = z[c][i]; \
+  zt[c][i] = fma(ha54, a4_, fma(ha53, a3_, fma(ha52, a2_, fma(ha51, a1_, zi_))));            \
+  k2[c][i] = fma(ha64, a4_, fma(ha63, a3_, fma(ha62, a2_, fma(ha61, a1_, zi_)))); /* Y6 */   \
+  k3[c][i] = fma(ha74, a4_, fma(ha73, a3_, fma(ha71, a1_, zi_)));                 /* Y7 */   \
+  k4[c][i] = fma(he4, a4_, fma(he3, a3_, he1 * a1_));                             /* E  */
+#define SBM_S6                                \
+  const double a5_ = k5[c][i];                \
+  zt[c][i] = fma(ha65, a5_, k2[c][i]);        \
+  k3[c][i] = fma(ha75, a5_, k3[c][i]);        \
+  k4[c][i] = fma(he5, a5_, k4[c][i]);
+#define SBM_S7                                \
+  const double a6_ = k6[c][i];                \
+  zt[c][i] = fma(ha76, a6_, k3[c][i]);        \
+  k4[c][i] = fma(he6, a6_, k4[c][i]);
+      SBM_ISSUE(t + C2 * hs, SBM_S2)
+      SBM_STAGE_THEN(t + C2 * hs, SBM_S2, k2, SBM_ISSUE(t + C3 * hs, SBM_S3))
+      SBM_STAGE_THEN(t + C3 * hs, SBM_S3, k3, SBM_ISSUE(t + C4 * hs, SBM_S4))
+      SBM_STAGE_THEN(t + C4 * hs, SBM_S4, k4, SBM_ISSUE(t + C5 * hs, SBM_S5))
+      SBM_STAGE_THEN(t + C5 * hs, SBM_S5, k5, SBM_ISSUE(t + hs, SBM_S6))
+      SBM_STAGE_THEN(t + hs, SBM_S6, k6, SBM_ISSUE(t + hs, SBM_S7))
+      // zt is the 5th-order solution now; k2 (Y6, dead) receives k7 = f(z_new) (FSAL)
+      SBM_STAGE_THEN(t + hs, SBM_S7, k2, )
+#undef SBM_S2
+#undef SBM_S3
+#undef SBM_S4
+#undef SBM_S5
+#undef SBM_S6
+#undef SBM_S7
+
+      // embedded error estimate E + h e7 k7; ratios and norm in f32 (they only steer the controller)
       // one sum of squares per column a lane holds (a lane of the row-group system holds the
       // rows of several columns next to each other inside one array: Sys::col_of maps them)
       float colsum[Sys::NCS];
@@ -361,8 +380,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       for (int c = 0; c < Sys::NCS; ++c) colsum[c] = 0.f;
       float xsum = 0.f;
       auto err_ratio = [&](int c, int i) {
-        const double e = fma(he7, k2[c][i],
-                             fma(he6, k6[c][i], fma(he5, k5[c][i], fma(he4, k4[c][i], fma(he3, k3[c][i], he1 * k1[c][i])))));
+        const double e = fma(he7, k2[c][i], k4[c][i]);
         const double sc = fma(rtol, fmax(fabs(z[c][i]), fabs(zt[c][i])), atol);
         return (float)e * __builtin_amdgcn_rcpf((float)sc);
       };
@@ -446,11 +464,11 @@ __device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::C
           const double ts = fma((double)s, hs, t0);
           sys.rhs(ts, z, k);
           SBM_ALL(c, i) acc[c][i] = k[c][i];
-          SBM_STAGE(ts + hh, fma(hh, k[c][i], z[c][i]), k)
+          SBM_STAGE(ts + hh, zt[c][i] = fma(hh, k[c][i], z[c][i]);, k)
           SBM_ALL(c, i) acc[c][i] = fma(2.0, k[c][i], acc[c][i]);
-          SBM_STAGE(ts + hh, fma(hh, k[c][i], z[c][i]), k)
+          SBM_STAGE(ts + hh, zt[c][i] = fma(hh, k[c][i], z[c][i]);, k)
           SBM_ALL(c, i) acc[c][i] = fma(2.0, k[c][i], acc[c][i]);
-          SBM_STAGE(ts + hs, fma(hs, k[c][i], z[c][i]), k)
+          SBM_STAGE(ts + hs, zt[c][i] = fma(hs, k[c][i], z[c][i]);, k)
           SBM_ALL(c, i) z[c][i] = fma(h6, acc[c][i] + k[c][i], z[c][i]);
         }
         out.n_acc += ns;
