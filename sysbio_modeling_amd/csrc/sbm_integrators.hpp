@@ -325,46 +325,48 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       bool last = false;
       if (t + 1.01 * hs >= target) { hs = target - t; last = true; }
 
-      const double ha21 = hs * A21;
-      const double ha31 = hs * A31, ha32 = hs * A32;
-      const double ha41 = hs * A41, ha42 = hs * A42, ha43 = hs * A43;
-      const double ha51 = hs * A51, ha52 = hs * A52, ha53 = hs * A53, ha54 = hs * A54;
-      const double ha61 = hs * A61, ha62 = hs * A62, ha63 = hs * A63, ha64 = hs * A64, ha65 = hs * A65;
-      const double ha71 = hs * A71, ha73 = hs * A73, ha74 = hs * A74, ha75 = hs * A75, ha76 = hs * A76;
-      const double he1 = hs * E1, he3 = hs * E3, he4 = hs * E4, he5 = hs * E5, he6 = hs * E6, he7 = hs * E7;
+      // The tableau entries stay compile-time constants (SGPR literals the compiler can rematerialise at
+      // will) and the step size multiplies each finished sum once: the 26 products h*a_ij, h*e_j would
+      // otherwise sit in 52 VGPRs for the whole step -- a fifth of the register budget of a wave that
+      // needs every register for its stage vectors (there is no scalar fp64 ALU to keep them in SGPRs).
+      // Price: one more FMA per element in stages 3-7.
+      //
       // Stages 2-4 combine the stored derivatives.  From stage 5 on every remaining linear
       // combination (the inputs of stages 6 and 7 and the error estimate) is carried as a RUNNING SUM
       // instead: when the input of stage 5 is formed, k2 / k3 / k4 are read one last time and their
-      // registers take over the partial sums Y6 / Y7 / E.  Same number of FMAs, but each derivative is
-      // read once instead of up to four times, and the live set peaks at 7 stage vectors instead of 8
-      // (z, k1, zt, Y6, Y7, E, k5), falling to 5 by stage 7 -- it is the v_accvgpr traffic of the
+      // registers take over the partial sums U6 / U7 / E (unscaled by h).  Each derivative is read
+      // once instead of up to four times and the live set peaks at 7 stage vectors instead of 8
+      // (z, k1, zt, U6, U7, E, k5), falling to 5 by stage 7 -- it is the v_accvgpr traffic of an
       // overflowing register file that this saves.
+      const double ha21 = hs * A21;
 #define SBM_S2 zt[c][i] = fma(ha21, k1[c][i], z[c][i]);
-#define SBM_S3 zt[c][i] = fma(ha32, k2[c][i], fma(ha31, k1[c][i], z[c][i]));
-#define SBM_S4 zt[c][i] = fma(ha43, k3[c][i], fma(ha42, k2[c][i], fma(ha41, k1[c][i], z[c][i])));
-#define SBM_S5                                                                              \
-  const double a1_ = k1[c][i], a2_ = k2[c][i], a3_ = k3[c][i], a4_ = k4[c][i], zi_ = z[c][i]; \
-  zt[c][i] = fma(ha54, a4_, fma(ha53, a3_, fma(ha52, a2_, fma(ha51, a1_, zi_))));            \
-  k2[c][i] = fma(ha64, a4_, fma(ha63, a3_, fma(ha62, a2_, fma(ha61, a1_, zi_)))); /* Y6 */   \
-  k3[c][i] = fma(ha74, a4_, fma(ha73, a3_, fma(ha71, a1_, zi_)));                 /* Y7 */   \
-  k4[c][i] = fma(he4, a4_, fma(he3, a3_, he1 * a1_));                             /* E  */
-#define SBM_S6                                \
-  const double a5_ = k5[c][i];                \
-  zt[c][i] = fma(ha65, a5_, k2[c][i]);        \
-  k3[c][i] = fma(ha75, a5_, k3[c][i]);        \
-  k4[c][i] = fma(he5, a5_, k4[c][i]);
-#define SBM_S7                                \
-  const double a6_ = k6[c][i];                \
-  zt[c][i] = fma(ha76, a6_, k3[c][i]);        \
-  k4[c][i] = fma(he6, a6_, k4[c][i]);
+#define SBM_S3 zt[c][i] = fma(hs, fma(A32, k2[c][i], A31 * k1[c][i]), z[c][i]);
+#define SBM_S4 zt[c][i] = fma(hs, fma(A43, k3[c][i], fma(A42, k2[c][i], A41 * k1[c][i])), z[c][i]);
+#define SBM_S5                                                                    \
+  const double a1_ = k1[c][i], a2_ = k2[c][i], a3_ = k3[c][i], a4_ = k4[c][i];    \
+  zt[c][i] = fma(hs, fma(A54, a4_, fma(A53, a3_, fma(A52, a2_, A51 * a1_))), z[c][i]); \
+  k2[c][i] = fma(A64, a4_, fma(A63, a3_, fma(A62, a2_, A61 * a1_))); /* U6 */     \
+  k3[c][i] = fma(A74, a4_, fma(A73, a3_, A71 * a1_));                /* U7 */     \
+  k4[c][i] = fma(E4, a4_, fma(E3, a3_, E1 * a1_));                   /* E  */
+#define SBM_S6                                              \
+  const double a5_ = k5[c][i];                              \
+  zt[c][i] = fma(hs, fma(A65, a5_, k2[c][i]), z[c][i]);     \
+  k3[c][i] = fma(A75, a5_, k3[c][i]);                       \
+  k4[c][i] = fma(E5, a5_, k4[c][i]);
+#define SBM_S7                                              \
+  const double a6_ = k6[c][i];                              \
+  zt[c][i] = fma(hs, fma(A76, a6_, k3[c][i]), z[c][i]);     \
+  k4[c][i] = fma(E6, a6_, k4[c][i]);
       SBM_ISSUE(t + C2 * hs, SBM_S2)
       SBM_STAGE_THEN(t + C2 * hs, SBM_S2, k2, SBM_ISSUE(t + C3 * hs, SBM_S3))
       SBM_STAGE_THEN(t + C3 * hs, SBM_S3, k3, SBM_ISSUE(t + C4 * hs, SBM_S4))
       SBM_STAGE_THEN(t + C4 * hs, SBM_S4, k4, SBM_ISSUE(t + C5 * hs, SBM_S5))
       SBM_STAGE_THEN(t + C5 * hs, SBM_S5, k5, SBM_ISSUE(t + hs, SBM_S6))
       SBM_STAGE_THEN(t + hs, SBM_S6, k6, SBM_ISSUE(t + hs, SBM_S7))
-      // zt is the 5th-order solution now; k2 (Y6, dead) receives k7 = f(z_new) (FSAL)
-      SBM_STAGE_THEN(t + hs, SBM_S7, k2, )
+      // zt is the 5th-order solution now.  k1 was last read when the input of stage 5 was formed, so
+      // k7 = f(z_new) goes straight into it: an accepted step continues with it (FSAL, no copy), a
+      // rejected one -- rare -- re-evaluates f(z).  One stage vector fewer alive through stages 5-7.
+      SBM_STAGE_THEN(t + hs, SBM_S7, k1, )
 #undef SBM_S2
 #undef SBM_S3
 #undef SBM_S4
@@ -372,7 +374,8 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
 #undef SBM_S6
 #undef SBM_S7
 
-      // embedded error estimate E + h e7 k7; ratios and norm in f32 (they only steer the controller)
+      // embedded error estimate h (E + e7 k7); ratios and norm in f32 (they only steer the controller).
+      // The norm is homogeneous: |h| multiplies it once at the end instead of every element.
       // one sum of squares per column a lane holds (a lane of the row-group system holds the
       // rows of several columns next to each other inside one array: Sys::col_of maps them)
       float colsum[Sys::NCS];
@@ -380,7 +383,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       for (int c = 0; c < Sys::NCS; ++c) colsum[c] = 0.f;
       float xsum = 0.f;
       auto err_ratio = [&](int c, int i) {
-        const double e = fma(he7, k2[c][i], k4[c][i]);
+        const double e = fma(E7, k1[c][i], k4[c][i]);
         const double sc = fma(rtol, fmax(fabs(z[c][i]), fabs(zt[c][i])), atol);
         return (float)e * __builtin_amdgcn_rcpf((float)sc);
       };
@@ -397,7 +400,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
           xsum = fmaf(r, r, xsum);
         }
       }
-      const float err = sys.norm(colsum, xsum);
+      const float err = fabsf((float)hs) * sys.norm(colsum, xsum);
 
       const bool finite = (err == err) && (err < 3.0e38f);
       const bool accept = finite && (err <= 1.0f);
@@ -412,7 +415,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
       if (accept) {
         ++out.n_acc;
         t = last ? target : t + hs;
-        SBM_ALL(c, i) { z[c][i] = zt[c][i]; k1[c][i] = k2[c][i]; }
+        SBM_ALL(c, i) z[c][i] = zt[c][i];
         const double hn = hs * (double)fac;
         // a step clipped to hit an output time says nothing against the unclipped proposal
         h = last ? fmax(hn, h) : hn;
@@ -422,6 +425,8 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
         if (!(h > 1e-14 * fmax(fabs(t), 1e-3))) {
           out.status = finite ? SBM_STEP_UNDERFLOW : SBM_NON_FINITE;
           failed = true;
+        } else {
+          sys.rhs(t, z, k1);   // k1 holds f(z_new) of the rejected attempt
         }
       }
     }
@@ -942,7 +947,10 @@ struct RowGroupSystem {
 };
 
 template <class M, int METHOD>
-__global__ void __launch_bounds__(64) sbm_sens_rowgroup_kernel(sbm_kernel_args a) {
+#ifndef SBM_RG_MIN_WAVES
+#define SBM_RG_MIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel(sbm_kernel_args a) {
   using Sys = RowGroupSystem<M, METHOD == SBM_RK4_FIXED>;
   using Sh = SbmRowGroupShared<M>;
   constexpr int MNV = M::NV, NK = M::NK;
