@@ -37,21 +37,27 @@ typedef struct sbm_project sbm_project;
 /* integrators.  The reference always uses LSODA at rtol = atol = 1e-10
  * (model/ode_model.py:122-123,167-168); these are the GPU replacements. */
 enum {
-  SBM_RK4_FIXED = 0, /* classic RK4, fixed step h0 between output times        */
-  SBM_DOPRI45 = 1    /* Dormand-Prince 5(4), error control on state AND sens.   */
+  SBM_RK4_FIXED = 0,        /* classic RK4, fixed step h0 between output times        */
+  SBM_DOPRI45 = 1,          /* Dormand-Prince 5(4), error control on state AND sens.   */
+  SBM_IMPLICIT_MIDPOINT = 2 /* stiff systems: implicit midpoint, fixed step h0, Newton with the
+                             * model's sparse LU; sensitivities = exact derivative of the scheme.
+                             * Second order with an h^2 error expansion (extrapolate two runs).
+                             * Needs n_vars <= 64 and n_sens <= 64. */
 };
 
 typedef struct sbm_integrator_opts {
-  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45                              */
+  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_IMPLICIT_MIDPOINT      */
   int32_t max_steps; /* per trajectory, accepted + rejected; <=0 -> 1000000      */
-  double rtol;       /* DOPRI45 relative tolerance                               */
-  double atol;       /* DOPRI45 absolute tolerance                               */
-  double h0;         /* RK4: step size; DOPRI45: initial step (<=0 -> automatic) */
+  double rtol;       /* DOPRI45 relative tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
+  double atol;       /* DOPRI45 absolute tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
+  double h0;         /* RK4, IMPLICIT_MIDPOINT: step size; DOPRI45: initial step (<=0 -> automatic) */
   double t0;         /* time of the initial condition; output times must be >= t0.
                       * odeint takes t_sim[0] for it (model/ode_model.py:122,167);
                       * Project always integrates from 0 (base_project.py:419)     */
   int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE | _ROW_GROUP */
-  int32_t reserved;  /* must be 0                                                       */
+  int32_t step_mult; /* fixed-step methods: every output interval is cut into
+                      * step_mult * ceil(dt / h0) equal steps (0 = 1).  Doubling it halves every
+                      * step exactly, which is what Richardson extrapolation needs.          */
 } sbm_integrator_opts;
 
 /* Three implementations of the sensitivity integrator with identical results up to
@@ -74,7 +80,8 @@ enum {
   SBM_OK = 0,
   SBM_MAX_STEPS = 1,
   SBM_NON_FINITE = 2,
-  SBM_STEP_UNDERFLOW = 3
+  SBM_STEP_UNDERFLOW = 3,
+  SBM_NEWTON_FAIL = 4   /* implicit midpoint: Newton did not converge in 12 iterations */
 };
 
 /* ---- context ----------------------------------------------------------- */

@@ -1,0 +1,94 @@
+"""ORACLE (test infrastructure, not product code) -- implicit midpoint with forward sensitivities.
+
+The reference has no implicit integrator of its own: stiff systems go to LSODA, which switches to
+BDF by itself (model/ode_model.py:122-123,167-168, optional analytic Jacobian ``Dfun`` :114-120).
+BASELINE configs[4] asks for an implicit-midpoint GPU integrator; this module restates THAT scheme
+on the CPU in dense numpy, step for step as csrc/sbm_integrators.hpp::sbm_imid_kernel runs it, so
+the kernel can be checked at the level of the algorithm (tests/test_gpu_implicit.py), while parity
+with the reference's results is checked against ``odeint_oracle`` (LSODA) after extrapolation.
+
+  y_{n+1} = y_n + h f(ybar), ybar = (y_n + y_{n+1})/2;  Newton from ybar = y_n:
+      (I - h/2 J_y(ybar)) delta = ybar - y_n - h/2 f(ybar),  ybar -= delta,
+      until max |delta_i| / (atol + rtol |ybar_i|) <= 1 (at most 12 iterations)
+  S_{n+1} = 2 Sbar - S_n,  (I - h/2 J_y) Sbar = S_n + h/2 J_p, with J_y, J_p of the last evaluated iterate
+  each output interval is cut into step_mult * ceil(dt / h0) equal steps.
+
+J_y and J_p are read off the generated sensitivity RHS (S' = J_y S + J_p): no second code path.
+Parity: "scheme-level" only -- pinned to LSODA through the convergence tests, not to reference vectors.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+MAXIT = 12
+
+
+def jacobians(gm, y, t, p):
+    """(f, J_y (n x n), J_p (n x k)) from the generated sens RHS, layout yout[n + i*k + j]."""
+    n, k = gm.n_vars, gm.n_sens
+    out = np.zeros(n + n * k)
+    aug = np.zeros(n + n * k)
+    aug[:n] = y
+    gm.sens_model(aug, t, out, p)
+    f = out[:n].copy()
+    Jp = out[n:].reshape(n, k).copy()
+    Jy = np.zeros((n, n))
+    # S = unit columns, k at a time
+    for start in range(0, n, max(k, 1)):
+        cols = range(start, min(start + k, n))
+        S = np.zeros((n, k))
+        for j, m in enumerate(cols):
+            S[m, j] = 1.0
+        aug[n:] = S.ravel()
+        gm.sens_model(aug, t, out, p)
+        full = out[n:].reshape(n, k) - Jp
+        for j, m in enumerate(cols):
+            Jy[:, m] = full[:, j]
+    return f, Jy, Jp
+
+
+def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None, with_sens=True, step_mult=1):
+    """Returns (Y (len(t_out), n), S (len(t_out), n*k) or None, n_steps, n_newton)."""
+    n, k = gm.n_vars, gm.n_sens
+    p = np.asarray(p, dtype=float)
+    y = np.zeros(n) if y0 is None else np.array(y0, dtype=float)
+    S = np.zeros((n, k)) if s0 is None else np.array(s0, dtype=float).reshape(n, k)
+    Y_out = np.zeros((len(t_out), n))
+    S_out = np.zeros((len(t_out), n * k))
+    t = float(t0)
+    n_steps = n_newton = 0
+    eye = np.eye(n)
+    for io, target in enumerate(t_out):
+        dt = target - t
+        if dt > 0:
+            nd = np.ceil(dt / h0 - 1e-9)
+            ns = (1 if nd < 1 else int(nd)) * step_mult
+            hs = dt / ns
+            hh = 0.5 * hs
+            t_start = t
+            for s in range(ns):
+                tm = t_start + (s + 0.5) * hs
+                yb = y.copy()
+                conv = False
+                for _ in range(MAXIT):
+                    n_newton += 1
+                    f, Jy, Jp = jacobians(gm, yb, tm, p)
+                    M = eye - hh * Jy
+                    delta = np.linalg.solve(M, (yb - y) - hh * f)
+                    yb = yb - delta
+                    if np.max(np.abs(delta) / (atol + rtol * np.abs(yb))) <= 1.0:
+                        conv = True
+                        break
+                if not conv:
+                    raise RuntimeError("Newton did not converge")
+                y = 2.0 * yb - y
+                if with_sens:
+                    Sb = np.linalg.solve(M, S + hh * Jp)
+                    S = 2.0 * Sb - S
+                n_steps += 1
+            t = target
+        Y_out[io] = y
+        S_out[io] = S.ravel()
+    return Y_out, (S_out if with_sens else None), n_steps, n_newton

@@ -15,7 +15,8 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
 SBM_RK4_FIXED = 0
 SBM_DOPRI45 = 1
-STATUS_NAMES = {0: 'ok', 1: 'max_steps', 2: 'non_finite', 3: 'step_underflow'}
+SBM_IMPLICIT_MIDPOINT = 2
+STATUS_NAMES = {0: 'ok', 1: 'max_steps', 2: 'non_finite', 3: 'step_underflow', 4: 'newton_fail'}
 
 
 class SbmError(RuntimeError):
@@ -25,7 +26,7 @@ class SbmError(RuntimeError):
 class IntegratorOpts(ctypes.Structure):
     _fields_ = [('method', ctypes.c_int32), ('max_steps', ctypes.c_int32),
                 ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double),
-                ('t0', ctypes.c_double), ('variant', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('t0', ctypes.c_double), ('variant', ctypes.c_int32), ('step_mult', ctypes.c_int32)]
 
 
 class ProjectDesc(ctypes.Structure):
@@ -125,28 +126,32 @@ def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+FIXED_STEP_IMPLICIT = ('implicit_midpoint', 'imid', 'midpoint')
 VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3}
 
 
 def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None, t0=0.0,
-              variant='auto'):
-    """IntegratorOpts from keywords.  For 'rk4' give h0 or (n_steps, t_end)."""
+              variant='auto', step_mult=0):
+    """IntegratorOpts from keywords.  For the fixed-step methods ('rk4', 'implicit_midpoint') give h0 or
+    (n_steps, t_end); rtol / atol are the Newton tolerances of 'implicit_midpoint'."""
     if isinstance(method, str):
         key = method.lower()
         if key in ('dopri45', 'dopri5', 'rk45'):
             m = SBM_DOPRI45
         elif key in ('rk4', 'rk4_fixed'):
             m = SBM_RK4_FIXED
+        elif key in FIXED_STEP_IMPLICIT:
+            m = SBM_IMPLICIT_MIDPOINT
         else:
-            raise ValueError("unknown integrator %r (use 'dopri45' or 'rk4')" % method)
+            raise ValueError("unknown integrator %r (use 'dopri45', 'rk4' or 'implicit_midpoint')" % method)
     else:
         m = int(method)
-    if m == SBM_RK4_FIXED and not h0 > 0.0:
+    if m in (SBM_RK4_FIXED, SBM_IMPLICIT_MIDPOINT) and not h0 > 0.0:
         if n_steps is None or t_end is None:
-            raise ValueError("rk4 needs h0, or n_steps together with t_end")
+            raise ValueError("a fixed-step method needs h0, or n_steps together with t_end")
         h0 = (float(t_end) - float(t0)) / int(n_steps)
     v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
-    return IntegratorOpts(m, int(max_steps), float(rtol), float(atol), float(h0), float(t0), v, 0)
+    return IntegratorOpts(m, int(max_steps), float(rtol), float(atol), float(h0), float(t0), v, int(step_mult))
 
 
 # ---------------------------------------------------------------------------

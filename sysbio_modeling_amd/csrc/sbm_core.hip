@@ -197,9 +197,12 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: RK4 needs h0 > 0", who);
   } else if (o->method == SBM_DOPRI45) {
     if (!(o->rtol > 0.0) || !(o->atol > 0.0)) return sbm_fail(SBM_E_ARG, "%s: DOPRI45 needs rtol, atol > 0", who);
+  } else if (o->method == SBM_IMPLICIT_MIDPOINT) {
+    if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: implicit midpoint needs h0 > 0", who);
   } else {
     return sbm_fail(SBM_E_ARG, "%s: unknown method %d", who, o->method);
   }
+  if (o->step_mult < 0 || o->step_mult > 65536) return sbm_fail(SBM_E_ARG, "%s: step_mult %d", who, o->step_mult);
   if (o->variant < SBM_VARIANT_AUTO || o->variant > SBM_VARIANT_ROW_GROUP)
     return sbm_fail(SBM_E_ARG, "%s: unknown kernel variant %d", who, o->variant);
   return 0;

@@ -459,7 +459,7 @@ __device__ __forceinline__ SbmTrajOut sbm_rk4(const Sys& sys, double (&z)[Sys::C
     const double target = t_out[io];
     const double dt = target - t;
     if (!failed && dt > 0.0) {
-      const double nd = ceil(dt / h0 - 1e-9);
+      const double nd = ceil(dt / h0 - 1e-9) * (o.step_mult > 0 ? o.step_mult : 1);
       int ns = nd < 1.0 ? 1 : (nd > 2.0e9 ? 2000000000 : (int)nd);
       if (out.n_acc + ns > max_steps) { out.status = SBM_MAX_STEPS; failed = true; }
       if (!failed) {
@@ -1045,6 +1045,174 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   }
 }
 
+// ===========================================================================
+// Implicit midpoint for stiff systems (BASELINE configs[4]), state + forward sensitivities.
+//
+//   y_{n+1} = y_n + h f(ybar),  ybar = (y_n + y_{n+1}) / 2      Newton on ybar:
+//       M(ybar) delta = ybar - y_n - (h/2) f(ybar),  M = I - (h/2) J_y(ybar)
+//   S_{n+1} = 2 Sbar - S_n,     M Sbar = S_n + (h/2) J_p(ybar)   -- the EXACT derivative of the scheme:
+//       one linear solve per sensitivity column with the matrix Newton just factored.
+// A-stable and symmetric (second order, error expansion in h^2: the host extrapolates two runs).
+//
+// Mapping: the row-lane one.  Lane j owns column j of S (all NV rows in VGPRs) and lane i the state
+// component y_i; row lanes evaluate f_i and the J_y / J_p entries of their row by class and publish them
+// in LDS.  M is the same for every lane of the wave: each lane builds and factors it redundantly with
+// the LU the model generator worked out symbolically for the model's sparsity pattern
+// (emit_implicit.py: straight-line code, static indices, fill-in included) -- for a cascade that is a
+// bidiagonal forward substitution, not a dense 50x50 solve -- then solves its own right-hand side:
+// the Newton residual (picked apart again: lane i keeps delta_i) and its sensitivity column.
+// Fixed step h0 between output times like RK4; opts.rtol / atol are the Newton tolerances.
+// ===========================================================================
+template <class M>
+struct SbmImidShared {
+  double Y[64];                 // iterate, one component per row lane
+  double G[64];                 // Newton residual, one component per row lane
+  double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
+  double A[M::NV * 64 + 2];     // A[i][c] = J_p[i][c] (+ spare slot)
+};
+
+template <class M>
+__global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
+  constexpr int NV = M::NV, NK = M::NK;
+  constexpr int MAXIT = 12;
+  static_assert(NV <= 64 && NK <= 64, "implicit midpoint kernel: one row and one column per lane");
+  __shared__ SbmImidShared<M> sh;
+  if ((int)blockIdx.x >= a.n_traj) return;
+  const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < NV * 64 + 2; i += 64) sh.A[i] = 0.0;
+  for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
+  sh.Y[lane] = 0.0;
+  sh.G[lane] = 0.0;
+
+  const bool has_row = lane < NV;
+  const bool has_col = lane < NK;
+  const int row = has_row ? lane : 0;
+  const int cls = has_row ? M::rl_class(row) : -1;
+  const double* P = a.P + (size_t)traj * M::NP;
+  int yidx[M::RL_MAXYS], jyout[M::RL_MAXJY], apos[M::RL_MAXJP];
+  double ps[M::RL_MAXPS];
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXYS; ++s) yidx[s] = M::rl_ys(s, row);
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXPS; ++s) ps[s] = P[M::rl_ps(s, row)];
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJY; ++s) jyout[s] = has_row ? M::rl_jyout(s, row) : M::NJY + 1;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJP; ++s) apos[s] = has_row ? M::rl_apos(s, row) : NV * 64 + 1;
+  __syncthreads();
+
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+  const bool with_sens = a.S != nullptr;   // wave-uniform
+
+  double z[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) z[i] = (a.s0 && has_col) ? a.s0[i * NK + lane] : 0.0;
+  double y = (a.y0 && has_row) ? a.y0[lane] : 0.0;
+
+  double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
+  double* St = a.S ? a.S + (size_t)traj * a.n_t * NV * NK : nullptr;
+  const double rtol = a.opts.rtol > 0.0 ? a.opts.rtol : 1e-10, atol = a.opts.atol > 0.0 ? a.opts.atol : 1e-12;
+  const double h0 = a.opts.h0;
+  const int max_steps = a.opts.max_steps > 0 ? a.opts.max_steps : 1000000000;
+  int status = SBM_OK, n_acc = 0, n_newton = 0;
+  double t = a.opts.t0;
+  bool failed = !(h0 > 0.0);
+  if (failed) status = SBM_STEP_UNDERFLOW;
+
+  double m[M::IM_NM];
+#pragma unroll
+  for (int e = 0; e < M::IM_NM; ++e) m[e] = 0.0;
+
+  for (int io = 0; io < glen; ++io) {
+    const double target = tg[io];
+    const double dt = target - t;
+    if (!failed && dt > 0.0) {
+      const double nd = ceil(dt / h0 - 1e-9) * (a.opts.step_mult > 0 ? a.opts.step_mult : 1);
+      const int ns = nd < 1.0 ? 1 : (nd > 2.0e9 ? 2000000000 : (int)nd);
+      if (n_acc + ns > max_steps) { status = SBM_MAX_STEPS; failed = true; }
+      if (!failed) {
+        const double hs = dt / ns, hh = 0.5 * hs;
+        const double t0 = t;
+        for (int s = 0; s < ns && !failed; ++s) {
+          const double tm = fma((double)s + 0.5, hs, t0);
+          double yb = y;
+          bool conv = false;
+          for (int it = 0; it < MAXIT && !conv; ++it) {
+            ++n_newton;
+            sh.Y[lane] = yb;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            double ys[M::RL_MAXYS];
+#pragma unroll
+            for (int q = 0; q < M::RL_MAXYS; ++q) ys[q] = sh.Y[yidx[q]];
+            double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+#pragma unroll
+            for (int q = 0; q < M::RL_MAXJY; ++q) jy[q] = 0.0;
+#pragma unroll
+            for (int q = 0; q < M::RL_MAXJP; ++q) jp[q] = 0.0;
+            M::class_dispatch(cls, tm, ys, ps, f, jy, jp);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+            for (int q = 0; q < M::RL_MAXJP; ++q) sh.A[apos[q]] = jp[q];
+#pragma unroll
+            for (int q = 0; q < M::RL_MAXJY; ++q) sh.JY[jyout[q]] = jy[q];
+            sh.G[lane] = has_row ? (yb - y) - hh * f : 0.0;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            M::im_build(hh, sh.JY, m);
+            M::im_factor(m);
+            double b[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) b[i] = sh.G[i];
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            M::im_solve(m, b);
+            double d = 0.0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) d = sbm_sel(lane == i, b[i], d);
+            yb -= d;
+            float r = has_row ? (float)(fabs(d) / fma(rtol, fabs(yb), atol)) : 0.f;
+            r = sbm_wave_max(sbm_nan_to_inf(r));
+            conv = r <= 1.0f;                       // wave-uniform
+            if (!(r < 3.0e38f)) { status = SBM_NON_FINITE; failed = true; break; }
+          }
+          if (!failed && !conv) { status = SBM_NEWTON_FAIL; failed = true; }
+          if (failed) break;
+          y = fma(2.0, yb, -y);
+          if (with_sens) {
+            // J_y (the factors in m) and J_p (A) are those of the last evaluated iterate: within the
+            // Newton tolerance of the converged midpoint
+            double b[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) b[i] = fma(hh, sh.A[i * 64 + lane], z[i]);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            M::im_solve(m, b);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) z[i] = fma(2.0, b[i], -z[i]);
+          }
+          ++n_acc;
+        }
+        if (!failed) t = target;
+      }
+    }
+    if (failed) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) z[i] = __builtin_nan("");
+      y = __builtin_nan("");
+    }
+    if (Yt && has_row) Yt[(size_t)io * NV + lane] = y;
+    if (St && has_col) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + lane] = z[i];
+    }
+  }
+  if (lane == 0) {
+    if (a.status) a.status[traj] = status;
+    if (a.n_steps) a.n_steps[traj] = n_acc;
+    if (a.n_reject) a.n_reject[traj] = n_newton - n_acc;   // Newton iterations beyond one per step
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host-side launcher used by sbm_plugin_main.hip
 // ---------------------------------------------------------------------------
@@ -1052,6 +1220,15 @@ template <class M>
 static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t stream) {
   const sbm_kernel_args a = *args;
   if (a.n_traj <= 0) return (int)hipSuccess;
+  if (a.opts.method == SBM_IMPLICIT_MIDPOINT) {
+    // one trajectory per wave for both kinds (state only: S == NULL skips the column work)
+    if constexpr (M::NV <= 64 && M::NK <= 64) {
+      hipLaunchKernelGGL((sbm_imid_kernel<M>), dim3(a.n_traj), dim3(64), 0, stream, a);
+      return (int)hipGetLastError();
+    } else {
+      return (int)hipErrorInvalidConfiguration;   // needs one row and one column per lane
+    }
+  }
   if (kind == SBM_KIND_SENS) {
     // row-lane kernel whenever the model fits one row + one column per lane and its rows fall into
     // few enough classes to pay (otherwise every class runs alone on a handful of lanes)

@@ -112,29 +112,54 @@ CASCADE_MEASURED_SPECIES = (4, 9, 14, 19)
 # ----------------------------------------------------------------------------
 # stiff50: 50-state signalling cascade with rate constants spanning 1e6
 # ----------------------------------------------------------------------------
-def stiff_spec(n=50, name=None):
-    """Linear-activation cascade with Michaelis-Menten deactivation.
+def stiff_spec(n=50, name=None, fixed_deactivation=True):
+    """Activation cascade with saturating deactivation, every species with its own time scale
+    (BASELINE configs[4]):
 
-    x_0' = a_0 (1 - x_0) - b_0 x_0/(0.1 + x_0);  x_i' = a_i x_{i-1} (1 - x_i) - b_i x_i/(0.1 + x_i).
-    Parameters a_0..a_{n-1} (activation), b_0.. (deactivation): 2n in total; the
-    nominal a_i span six decades, which is what makes the system stiff.
+        x_0' = a_0 ((1 - x_0)         - b_0 x_0 / (1/2 + x_0))
+        x_i' = a_i (x_{i-1} (1 - x_i) - b_i x_i / (1/2 + x_i))
+
+    a_i is the RATE of species i (its steady state does not depend on it); nominal a_i = 10^(6 i/(n-1)):
+    1 at the top of the cascade, 10^6 at the bottom -- the fast species follow the slow ones
+    quasi-statically, which is what makes the system stiff (stiffness ratio 10^7 over t_end = 10) while
+    the stage gains stay O(1) (a well-conditioned problem: an ultrasensitive variant amplified rounding
+    errors by 10^9 along the cascade and no two integrators agreed on it).  Starting from y0 = 0 every
+    fast species starts on its quasi-steady state: no initial layer.  Parameters a_0.. (rates) and b_0..
+    (deactivation strengths, nominal 0.5); with ``fixed_deactivation`` the b_i are 'fixed' parameters
+    (no sensitivity columns): k = n sensitivity parameters, N = n + n*n = 2550 coupled ODEs at n = 50, as
+    SURVEY.md section 8(d) sizes config 5.
     """
     xs = [Symbol('x%d' % i) for i in range(n)]
     a = [Symbol('a%d' % i) for i in range(n)]
     b = [Symbol('b%d' % i) for i in range(n)]
-    tenth = sympy.Rational(1, 10)
+    half = sympy.Rational(1, 2)
     eq = OrderedDict()
-    eq['x0'] = a[0] * (1 - xs[0]) - b[0] * xs[0] / (tenth + xs[0])
+    eq['x0'] = a[0] * ((1 - xs[0]) - b[0] * xs[0] / (half + xs[0]))
     for i in range(1, n):
-        eq['x%d' % i] = a[i] * xs[i - 1] * (1 - xs[i]) - b[i] * xs[i] / (tenth + xs[i])
+        eq['x%d' % i] = a[i] * (xs[i - 1] * (1 - xs[i]) - b[i] * xs[i] / (half + xs[i]))
     return ModelSpec(name=name or ('stiff%d' % n), variables=[str(x) for x in xs],
-                     params=[str(s) for s in a] + [str(s) for s in b], equations=eq)
+                     params=[str(s) for s in a] + [str(s) for s in b], equations=eq,
+                     fixed=[str(s) for s in b] if fixed_deactivation else [])
 
 
 def stiff_nominal_params(n=50):
-    a = 10.0 ** np.linspace(-2.0, 4.0, n)
+    a = 10.0 ** np.linspace(0.0, 6.0, n)
     b = 0.5 * np.ones(n)
     return np.concatenate([a, b])
+
+
+STIFF_T_END = 10.0
+STIFF_MEASURE_TIMES = np.linspace(0.625, 10.0, 16)
+
+
+def stiff_ensemble(n_vectors=4096, n=50, seed=20261003, spread=0.25):
+    """theta_v = log(p_nom) + spread * z on the activation rates; deactivation rates stay nominal (they are
+    'fixed' parameters of the model).  Returns (theta, p), row-major (V, 2n)."""
+    rng = np.random.default_rng(seed)
+    p_nom = stiff_nominal_params(n)
+    theta = np.tile(np.log(p_nom), (n_vectors, 1))
+    theta[:, :n] += spread * rng.standard_normal((n_vectors, n))
+    return theta, np.exp(theta)
 
 
 # ----------------------------------------------------------------------------

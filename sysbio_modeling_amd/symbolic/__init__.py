@@ -149,4 +149,4 @@ def zoo_model(name):
     return gm
 
 
-ZOO_NAMES = ('simple', 'michaelis_menten', 'cascade20')
+ZOO_NAMES = ('simple', 'michaelis_menten', 'cascade20', 'stiff50')

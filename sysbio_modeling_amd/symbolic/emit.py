@@ -23,6 +23,7 @@ from sympy.printing.c import C99CodePrinter
 from . import sympy_tools
 from . import emit_rowlane
 from . import emit_rowgroup
+from . import emit_implicit
 
 
 _RCP = sympy.Function('SBM_RCP')
@@ -425,5 +426,6 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     L += emit_rowlane.emit_rowlane_members(spec, d, rl_meta,
                                            lambda smap: _ExprPrinter(smap, rcp="SBM_RCP(%s)", lang='hip'))
     L += [""] + emit_rowgroup.emit_members(spec, d, rg_layout)
+    L += [""] + emit_implicit.emit_members(spec, d)
     L += ["};", ""]
     return "\n".join(L)

@@ -159,4 +159,16 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
     return 0;
   }
 }
+
+// b <- (I - gamma*J_y(y))^-1 b through the generated sparse LU (im_build / im_factor / im_solve)
+void h_im_solve(double gamma, const double* y, double t, const double* p, double* b) {
+  using M = SbmModel;
+  double yy[M::NV], f[M::NV], jy[M::NJY], jp[M::NJP], m[M::IM_NM], bb[M::NV];
+  for (int i = 0; i < M::NV; ++i) { yy[i] = y[i]; bb[i] = b[i]; }
+  M::eval_jac(t, yy, p, f, jy, jp);
+  M::im_build(gamma, jy, m);
+  M::im_factor(m);
+  M::im_solve(m, bb);
+  for (int i = 0; i < M::NV; ++i) b[i] = bb[i];
+}
 }

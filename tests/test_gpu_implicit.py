@@ -1,0 +1,109 @@
+"""Implicit midpoint on the GPU (BASELINE configs[4]: stiff 50-state cascade, N = 2550 coupled ODEs).
+
+Two levels of parity:
+  * scheme level: csrc/sbm_integrators.hpp::sbm_imid_kernel against oracle/imid_oracle.py, the same
+    algorithm in dense numpy (same steps, same Newton recipe): agreement to rounding;
+  * reference level: against SciPy odeint (LSODA switches to BDF on this system) -- second-order
+    convergence of the raw scheme and agreement of the Richardson-extrapolated result.
+The model's sparse LU (emit_implicit.py) is exercised on three sparsity patterns: bidiagonal
+(stiff50), bidiagonal + corner with fill-in (cascade20) and a 2x2 block (Michaelis-Menten)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from tests import reference_cases as rc
+from tests.conftest import parity_err
+
+pytestmark = pytest.mark.gpu
+
+IM = dict(method='implicit_midpoint', rtol=1e-10, atol=1e-12)
+
+
+def _from_zero(t_pts):
+    return np.concatenate([[0.0], np.asarray(t_pts, dtype=float)])
+
+
+@pytest.mark.parametrize('name,t_end,h0', [('michaelis_menten', 100.0, 2.0), ('cascade20', 100.0, 1.0),
+                                            ('stiff50', 10.0, 0.02)])
+def test_kernel_equals_scheme_oracle(gpu_models, zoo, name, t_end, h0):
+    from oracle import imid_oracle
+    from sysbio_modeling_amd import models_zoo
+    gm, m = zoo(name), gpu_models(name)
+    if name == 'michaelis_menten':
+        P = np.stack([rc.MM_PARAMS * np.array([40.0, 30.0, 5.0, 3.0, 20.0]), rc.MM_PARAMS * 7.0])
+    elif name == 'cascade20':
+        P = models_zoo.cascade_ensemble(2)[1]
+    else:
+        P = models_zoo.stiff_ensemble(2)[1]
+    t_out = np.array([0.0, 0.37 * t_end, t_end])
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, h0=h0, **IM)
+    assert m.last_info['status'].tolist() == [0, 0]
+    for v in range(2):
+        Yo, So, ns, nn = imid_oracle.integrate(gm, P[v], t_out[1:], h0)
+        assert m.last_info['n_steps'][v] == ns
+        # Newton iterations beyond one per step: the stopping test sits on a knife edge now and then
+        assert abs(int(m.last_info['n_rejected'][v]) - (nn - ns)) <= (nn - ns) // 8 + 2
+        assert np.allclose(Y[v, 1:], Yo, rtol=1e-9, atol=1e-12)
+        assert np.allclose(S[v, 1:], So, rtol=1e-8, atol=1e-10 * np.abs(So).max())
+    # state-only entry point: same kernel without the column work
+    Y2 = m.simulate_batch(P, t_out, h0=h0, **IM)
+    assert np.array_equal(Y2, Y)
+
+
+def test_stiff50_against_reference_golden(gpu_models, golden):
+    """tests/golden/stiff50_ref.npz: the REAL reference OdeModel (LSODA, which switches to BDF here) on
+    the build's stiff50 model, 3 vectors, 16 measurement rows (make_golden_stiff.py).  Raw scheme: error
+    / 4 per halving of h; one Richardson level on 4096 + 8192 steps meets the parity tolerance of the
+    explicit kernels (|gpu - ref| <= 1e-8 |ref| + 5e-9).  Explicit RK4 at the same step count blows up:
+    the system IS stiff."""
+    m = gpu_models('stiff50')
+    g = golden('stiff50_ref.npz')
+    P, Yr, Sr = g['P'], g['Y'], g['S']
+    t_out = _from_zero(g['t'][g['idx']])
+    errs = []
+    for mult in (1, 2):
+        S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, n_steps=1024, step_mult=mult, **IM)
+        assert m.last_info['status'].tolist() == [0, 0, 0]
+        errs.append((np.max(np.abs(Y[:, 1:] - Yr)), np.max(np.abs(S[:, 1:] - Sr))))
+    assert 3.6 < errs[0][0] / errs[1][0] < 4.4 and 3.6 < errs[0][1] / errs[1][1] < 4.4
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, n_steps=4096, extrapolate=1, **IM)
+    assert m.last_info['status'].tolist() == [0, 0, 0]
+    assert parity_err(Y[:, 1:], Yr) <= 1.0
+    assert parity_err(S[:, 1:], Sr) <= 1.0
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Yx = m.simulate_batch(P, t_out, method='rk4', n_steps=4096)
+    assert not np.all(np.isfinite(Yx)) or np.max(np.abs(Yx[:, 1:] - Yr)) > 1e-2
+
+
+def test_newton_failure_is_reported_per_trajectory(gpu_models):
+    from sysbio_modeling_amd import models_zoo
+    m = gpu_models('stiff50')
+    _, P = models_zoo.stiff_ensemble(3)
+    P[1, 3] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Y = m.simulate_batch(P, np.array([0.0, 1.0]), h0=0.01, **IM)
+    assert m.last_info['status'][1] != 0 and np.all(np.isnan(Y[1, -1]))
+    assert m.last_info['status'][[0, 2]].tolist() == [0, 0] and np.all(np.isfinite(Y[[0, 2]]))
+
+
+def test_config5_full_ensemble_properties(gpu_models):
+    """BASELINE configs[4] at full size: 4096 vectors x 2550 ODEs.  Size-independent properties:
+    states stay in [0, 1] (the model's invariant region), sensitivities of species i to a_j vanish
+    for j > i (the cascade is feed-forward), permutation equivariance, determinism."""
+    from sysbio_modeling_amd import models_zoo
+    m = gpu_models('stiff50')
+    _, P = models_zoo.stiff_ensemble(4096)
+    t_out = np.array([0.0, 2.5, models_zoo.STIFF_T_END])
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, n_steps=512, **IM)
+    assert not m.last_info['status'].any()
+    assert Y.min() >= 0.0 and Y.max() < 1.0
+    S4 = S.reshape(4096, 3, 50, 50)
+    upper = np.triu_indices(50, k=1)
+    assert np.all(S4[:, :, upper[0], upper[1]] == 0.0)
+    assert np.abs(S4[:, -1, np.arange(50), np.arange(50)]).min() > 0.0
+    perm = np.random.default_rng(0).permutation(4096)[:512]
+    S2 = m.calc_jacobian_batch(P[perm], t_out, n_steps=512, **IM)
+    assert np.array_equal(S2, S[perm])
