@@ -255,6 +255,34 @@ def main():
                                                      "rows": 512, "params": 68,
                                                      "failed_vectors": int((o4['status'] != 0).sum().item())}
 
+        # BASELINE configs[4]: stiff 50-state cascade, 2550 coupled ODEs, implicit midpoint, 4096 vectors.
+        # One launch per Richardson level; the parity setting of tests/test_gpu_implicit.py is 4096 + 8192
+        # steps (extrapolate=1), timed here: the 2048-step launch, whose cost scales linearly.
+        gm5 = zoo_model('stiff50')
+        m5 = OdeModel(gm5.model, gm5.sens_model, gm5.n_vars, gm5.param_order, use_jit=False)
+        P5 = torch.from_numpy(models_zoo.stiff_ensemble(4096)[1]).to(dev)
+        t5 = torch.tensor([5.0, models_zoo.STIFF_T_END], dtype=f64, device=dev)
+        Y5 = torch.empty((4096, 2, 50), dtype=f64, device=dev)
+        S5 = torch.empty((4096, 2, 50, 50), dtype=f64, device=dev)
+        st5 = torch.empty((4096,), dtype=i32, device=dev)
+        ns5 = torch.empty((4096,), dtype=i32, device=dev)
+        nw5 = torch.empty((4096,), dtype=i32, device=dev)
+        o5 = _lib.make_opts('implicit_midpoint', rtol=1e-10, atol=1e-12, n_steps=2048, t_end=models_zoo.STIFF_T_END)
+        m5.device_model.sens_dev(P5, t5, None, o5, Y5, S5, st5, ns5, nw5)
+        torch.cuda.synchronize(dev)
+        a5, b5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a5.record()
+        m5.device_model.sens_dev(P5, t5, None, o5, Y5, S5, st5, ns5, nw5)
+        b5.record()
+        torch.cuda.synchronize(dev)
+        ms5 = a5.elapsed_time(b5)
+        n5 = int(ns5.sum().item())
+        extras["configs4_stiff50_implicit_midpoint_2048_steps"] = {
+            "ms": ms5, "steps": n5, "steps_per_s": n5 / (ms5 * 1e-3), "n_equations": 2550,
+            "newton_iterations_per_step": 1.0 + float(nw5.sum().item()) / n5,
+            "algorithmic_GBps": n5 / (ms5 * 1e-3) * 2 * 8 * 2550 / 1e9,
+            "failed_vectors": int((st5 != 0).sum().item())}
+
     result = {
         "metric": "ensemble ODE-steps/sec (20-state model + fwd sens)",
         "value": value, "unit": "ODE-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
