@@ -88,6 +88,44 @@ def cpu_baseline(gm, theta_rows, budget_s=12.0, max_vectors=4096):
             "ms_per_vector": 1e3 * dt / max(n, 1)}
 
 
+def _cpu_worker(rows_budget):
+    """one process of the all-cores baseline: integrates its share of the sample for `budget` seconds"""
+    rows, budget = rows_budget
+    from sysbio_modeling_amd.symbolic import zoo_model
+    from oracle import odeint_oracle as oo
+    gm = zoo_model('cascade20')
+    gm.c_library()
+    grid = np.linspace(0, 100.0, 1000)
+    steps, n, t0 = 0, 0, time.perf_counter()
+    for row in rows:
+        _, info = oo.calc_jacobian(gm, np.exp(row), grid, use_c=True, full_output=True)
+        steps += int(info['nst'][-1])
+        n += 1
+        if time.perf_counter() - t0 > budget:
+            break
+    return steps, n, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(theta_rows, budget_s=10.0):
+    """The same oracle on every host core the process may use: one worker
+    process per core, each timing its own share.  Runs BEFORE this process touches the GPU (the workers
+    are spawned, not forked)."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    per = max(1, len(theta_rows) // cores)
+    # every worker starts at its own offset of the ensemble and stops on its time budget
+    chunks = [(np.roll(theta_rows, -i * per, axis=0), budget_s) for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context('spawn').Pool(cores) as pool:
+        out = pool.map(_cpu_worker, chunks)
+    rate = sum(st / dt for st, _, dt in out)          # every worker timed on its own clock
+    return {"value": rate, "unit": "ODE-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d vectors over %d worker processes, %.1f s each (wall %.1f s incl. start-up); same "
+                      "odeint call as cpu_baseline" % (sum(n for _, n, _ in out), cores, budget_s,
+                                                       time.perf_counter() - t0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -98,13 +136,24 @@ def main():
     ap.add_argument('--rk4-steps', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help="time the CPU oracle and exit (no GPU needed)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    cpu_all = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from sysbio_modeling_amd import models_zoo as _mz
+        cpu_all = cpu_baseline_all_cores(_mz.cascade_ensemble(args.vectors)[0])
+    if args.cpu_baseline_only:
+        from sysbio_modeling_amd.symbolic import zoo_model as _zm
+        from sysbio_modeling_amd import models_zoo as _mz
+        print(json.dumps({"cpu_baseline": cpu_baseline(_zm('cascade20'), _mz.cascade_ensemble(args.vectors)[0]),
+                          "cpu_baseline_all_cores": cpu_all}))
+        return
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -300,6 +349,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(gm, theta)
+        result["cpu_baseline_all_cores"] = cpu_all
     elif rank == 0:
         result["cpu_baseline"] = None
     if extras:
