@@ -658,6 +658,43 @@ class Project(object):
     def calc_sum_square_residuals_batch(self, thetas, **integrator_overrides):
         return 0.5 * self.evaluate_batch(thetas, **integrator_overrides)['norms']
 
+    def calc_scale_factors_entropy(self, temperature=1.0, sims=None):
+        """Sum over the scale-factor groups of T * log-integral entropy terms (reference :854-872,
+        abstract_loss_function.py:122-134, linear_scale_factor.py:63-81) for the simulations of the last
+        evaluation (or ``sims``, one unscaled value per measurement row).  Every group needs a log prior,
+        as in the reference.  Host-side quadrature on device-computed simulations."""
+        from .loss_functions.squared_loss.linear_scale_factor import scale_factor_entropy
+        if sims is None:
+            if 'sims' not in self._last:
+                raise ValueError("no simulation yet: call residuals() first")
+            sims = self._last['sims']
+        a = self.descriptor_arrays()
+        grp, d, sg = a['row_sf'], a['row_data'], a['row_sigma']
+        entropy = 0.0
+        for gi, sf in enumerate(self._loss_function._scale_factors.values()):
+            if sf.log_prior is None:
+                raise ValueError("scale factor entropy needs a log prior on every scale factor "
+                                 "(set_scale_factor_log_prior)")
+            sel = grp == gi
+            w = 1.0 / sg[sel] ** 2
+            entropy += temperature * scale_factor_entropy(np.sum(sims[sel] ** 2 * w), np.sum(sims[sel] * d[sel] * w),
+                                                          sf.log_prior, sf.log_prior_sigma, temperature)
+        return entropy
+
+    def free_energy(self, project_param_vector, temperature=1):
+        """rss - scale-factor entropy (reference :874-892)."""
+        rss = self.calc_sum_square_residuals(project_param_vector)
+        return rss - self.calc_scale_factors_entropy(temperature)
+
+    def free_energy_batch(self, thetas, temperature=1, **integrator_overrides):
+        """free_energy for V parameter vectors: one batched device evaluation, then the quadratures."""
+        res = self.evaluate_batch(thetas, **integrator_overrides)
+        out = 0.5 * res['norms']
+        for v in range(len(out)):
+            out[v] = out[v] - self.calc_scale_factors_entropy(temperature, sims=res['sims'][v]) \
+                if np.isfinite(out[v]) else np.inf
+        return out
+
     def nlopt_fcn(self, project_param_vector, grad):
         """nlopt-style objective: fills ``grad`` in place when it is non-empty (reference :829-852)."""
         if grad.size > 0:

@@ -652,3 +652,34 @@ def test_launch_order_does_not_change_results(gpu_models):
     assert np.array_equal(S3, S1[::-1])
     S4 = m.calc_jacobian_batch(P3[:100], t_out)     # small batches bypass the ordering
     assert np.array_equal(S4, S3[:100])
+
+
+def test_free_energy_and_scale_factor_entropy(gpu_models, zoo):
+    """Project.free_energy = rss - T * sum_groups log-integral (reference base_project.py:854-892,
+    linear_scale_factor.py:13-18,63-81), against an independent evaluation: oracle simulations, the
+    integral by the trapezoid rule on a dense u grid."""
+    from oracle.project_oracle import ProjectOracle
+    from sysbio_modeling_amd.project import Project
+    exps, settings, mapping, sf = rc.simple_project_case()
+    proj = Project(gpu_models('simple'), exps, settings, mapping, sf_groups=sf)
+    exps2, _, _, _ = rc.simple_project_case()
+    po = ProjectOracle(zoo('simple'), exps2, settings, mapping, sf_groups=sf)
+    theta = rc.simple_project_theta(proj.get_param_index) + 0.05
+    with pytest.raises(ValueError):
+        proj.free_energy(theta)                       # no log prior on the scale factor
+    proj.set_scale_factor_log_prior('Variable_1', np.log(3.0), 0.5)
+    po.set_scale_factor_log_prior('Variable_1', np.log(3.0), 0.5)
+    for T in (1.0, 2.5):
+        fe = proj.free_energy(theta, T)
+        res, sims, B = po.residuals(theta, return_parts=True)
+        rows = po.rows()
+        d = np.array([r[2] for r in rows]); sg = np.array([r[3] for r in rows])
+        ak, bk = np.sum(sims ** 2 / sg ** 2), np.sum(sims * d / sg ** 2)
+        u = np.linspace(-6, 6, 400001)
+        b = np.exp(u) * bk / ak
+        f = np.exp(-ak / (2 * T) * (b - bk / ak) ** 2 - (u + np.log(bk / ak) - np.log(3.0)) ** 2 / (2 * 0.25))
+        integral = np.sum(0.5 * (f[1:] + f[:-1])) * (u[1] - u[0])
+        ref = 0.5 * np.sum(res ** 2) - T * np.log(integral)
+        assert fe == pytest.approx(ref, rel=1e-7)
+    fb = proj.free_energy_batch(np.stack([theta, theta + 0.1]), 1.0)
+    assert fb[0] == pytest.approx(proj.free_energy(theta, 1.0), rel=1e-12) and np.isfinite(fb[1])
