@@ -275,6 +275,24 @@ int sbm_loss_eval_host(sbm_ctx* ctx, const sbm_loss_desc* desc, int32_t V, const
                        const double* Jm, double* R, double* J, double* sf, double* sf_grad,
                        double* norms, int32_t* status);
 
+/* ---- batched Levenberg-Marquardt step ---------------------------------- */
+/* The caller after the path.  The reference fits one start at a time with
+ * scipy.optimize.leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)
+ * (tests/test_Project.py:202-213, :352-357); here every vector of an ensemble
+ * takes its own damped Gauss-Newton step on the device:
+ *     (J^T J + lambda_v diag(J^T J)) delta_v = -J^T r_v.
+ * J      [V][M][q]  in  d r / d theta as sbm_jacobian_batch returns it with reference_compat = 0
+ * r      [V][M]     in  residuals
+ * lambda [V]        in  damping, >= 0
+ * delta  [V][q]     out step
+ * pred   [V]        out predicted decrease of 0.5 |r|^2 (Gauss-Newton model)
+ * status [V]        out 0, or 1 where the system is not positive definite / the input not finite
+ *                       (delta = 0: raise lambda)
+ * Device pointers; q <= 128; enqueued on the context's stream. */
+int sbm_lm_step(sbm_ctx* ctx, const double* J_dev, const double* r_dev, const double* lambda_dev,
+                int32_t V, int32_t M, int32_t q, double* delta_dev, double* pred_dev,
+                int32_t* status_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -996,3 +996,157 @@ extern "C" int sbm_loss_eval_host(sbm_ctx* ctx, const sbm_loss_desc* d, int32_t 
   if (e != hipSuccess || e2 != hipSuccess) return sbm_fail(SBM_E_HIP, "%s: %s", who, hipGetErrorString(e != hipSuccess ? e : e2));
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Batched Levenberg-Marquardt step (the caller after the path: multi-start fitting).
+// The reference fits with scipy.optimize.leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)
+// (tests/test_Project.py:202-213, :352-357), one start at a time; here every parameter vector of an
+// ensemble takes its own damped Gauss-Newton step:
+//     (J^T J + lambda_v diag(J^T J)) delta_v = -J^T r_v          (Marquardt scaling)
+// One 256-thread block per vector: J^T J and J^T r accumulated from row tiles staged in LDS,
+// Cholesky and the two triangular solves in LDS.  q <= 128.
+// ---------------------------------------------------------------------------------------------
+struct LmArgs {
+  const double* J;       // [V][M][q]
+  const double* r;       // [V][M]
+  const double* lambda;  // [V]
+  double* delta;         // [V][q]
+  double* pred;          // [V] predicted decrease of 0.5 |r|^2: -g.delta - 0.5 delta^T (J^T J) delta
+  int32_t* status;       // [V] 0 ok, 1 not positive definite / non-finite input (delta = 0)
+  int M, q;
+};
+
+constexpr int LM_TILE = 32;   // rows of J staged per pass
+
+__global__ void __launch_bounds__(256) k_lm_step(LmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lm_smem[];
+  const int v = blockIdx.x, tid = threadIdx.x, q = a.q, M = a.M;
+  const int ld = q + 1;                      // padded leading dimension of the q x q matrices
+  double* A = lm_smem;                       // [q][ld]  J^T J, then its Cholesky factor (lower)
+  double* H = A + (size_t)q * ld;            // [q][ld]  copy of J^T J for the predicted decrease
+  double* g = H + (size_t)q * ld;            // [q]      J^T r
+  double* x = g + q;                         // [q]      solution
+  double* T = x + q;                         // [LM_TILE][ld] row tile of J
+  double* rt = T + (size_t)LM_TILE * ld;     // [LM_TILE]
+  __shared__ int s_bad;
+  if (tid == 0) s_bad = 0;
+  const double* Jv = a.J + (size_t)v * M * q;
+  const double* rv = a.r + (size_t)v * M;
+  // each thread owns the entries e = tid, tid + 256, ... of the lower triangle (i >= j) and of g
+  const int n_low = q * (q + 1) / 2;
+  constexpr int MAXOWN = (128 * 129 / 2 + 255) / 256;
+  double acc[MAXOWN];
+  int oi[MAXOWN], oj[MAXOWN];
+  int n_own = 0;
+  for (int e = tid; e < n_low; e += 256) {
+    // row i with i(i+1)/2 <= e
+    int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    while (i * (i + 1) / 2 > e) --i;
+    oi[n_own] = i; oj[n_own] = e - i * (i + 1) / 2; acc[n_own] = 0.0; ++n_own;
+  }
+  double gacc = 0.0;   // thread c < q owns g[c]
+  for (int m0 = 0; m0 < M; m0 += LM_TILE) {
+    const int rows = min(LM_TILE, M - m0);
+    __syncthreads();
+    for (int e = tid; e < rows * q; e += 256) {
+      const int rr = e / q, c = e - rr * q;
+      const double val = Jv[(size_t)(m0 + rr) * q + c];
+      T[rr * ld + c] = val;
+      if (!(fabs(val) < 1.0e300)) s_bad = 1;
+    }
+    for (int e = tid; e < rows; e += 256) {
+      const double val = rv[m0 + e];
+      rt[e] = val;
+      if (!(fabs(val) < 1.0e300)) s_bad = 1;
+    }
+    __syncthreads();
+    for (int k = 0; k < n_own; ++k) {
+      double s = acc[k];
+      for (int rr = 0; rr < rows; ++rr) s = fma(T[rr * ld + oi[k]], T[rr * ld + oj[k]], s);
+      acc[k] = s;
+    }
+    if (tid < q) {
+      double s = gacc;
+      for (int rr = 0; rr < rows; ++rr) s = fma(T[rr * ld + tid], rt[rr], s);
+      gacc = s;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < n_own; ++k) {
+    A[oi[k] * ld + oj[k]] = acc[k];
+    H[oi[k] * ld + oj[k]] = acc[k];
+    H[oj[k] * ld + oi[k]] = acc[k];
+  }
+  if (tid < q) g[tid] = gacc;
+  __syncthreads();
+  const double lam = a.lambda[v];
+  if (tid < q) {
+    const double d = A[tid * ld + tid];
+    // Marquardt scaling; a column J never touches (d = 0) gets a unit pivot: delta_c = 0
+    A[tid * ld + tid] = d > 0.0 ? d * (1.0 + lam) : 1.0;
+  }
+  __syncthreads();
+  bool bad = s_bad != 0 || !(lam >= 0.0);
+  // right-looking Cholesky, lower triangle in place
+  for (int k = 0; k < q && !bad; ++k) {
+    const double piv = A[k * ld + k];
+    if (!(piv > 0.0) || !(piv < 1.0e300)) { bad = true; break; }   // uniform: every thread reads the same value
+    const double rp = 1.0 / sqrt(piv);
+    __syncthreads();
+    if (tid == 0) A[k * ld + k] = sqrt(piv);
+    for (int i = k + 1 + tid; i < q; i += 256) A[i * ld + k] *= rp;
+    __syncthreads();
+    // trailing update: entries (i, j), k < j <= i
+    const int nt = q - k - 1;
+    for (int e = tid; e < nt * nt; e += 256) {
+      const int i = k + 1 + e / nt, j = k + 1 + e % nt;
+      if (j <= i) A[i * ld + j] = fma(-A[i * ld + k], A[j * ld + k], A[i * ld + j]);
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    for (int c = tid; c < q; c += 256) a.delta[(size_t)v * q + c] = 0.0;
+    if (tid == 0) { a.pred[v] = 0.0; a.status[v] = 1; }
+    return;
+  }
+  // L y = -g ; L^T x = y   (q is small: one thread, the other 255 wait)
+  if (tid == 0) {
+    for (int i = 0; i < q; ++i) {
+      double s = -g[i];
+      for (int j = 0; j < i; ++j) s = fma(-A[i * ld + j], x[j], s);
+      x[i] = s / A[i * ld + i];
+    }
+    for (int i = q - 1; i >= 0; --i) {
+      double s = x[i];
+      for (int j = i + 1; j < q; ++j) s = fma(-A[j * ld + i], x[j], s);
+      x[i] = s / A[i * ld + i];
+    }
+  }
+  __syncthreads();
+  double part = 0.0;
+  if (tid < q) {
+    a.delta[(size_t)v * q + tid] = x[tid];
+    double hx = 0.0;
+    for (int j = 0; j < q; ++j) hx = fma(H[tid * ld + j], x[j], hx);
+    part = -x[tid] * (g[tid] + 0.5 * hx);
+  }
+  __shared__ double s_red[4];
+  const double tot = block_sum(part, s_red);
+  if (tid == 0) { a.pred[v] = tot; a.status[v] = 0; }
+}
+
+extern "C" int sbm_lm_step(sbm_ctx* ctx, const double* J, const double* r, const double* lambda, int32_t V, int32_t M,
+                           int32_t q, double* delta, double* pred, int32_t* status) {
+  if (!ctx || !J || !r || !lambda || !delta || !pred || !status) return sbm_fail(SBM_E_ARG, "sbm_lm_step: NULL argument");
+  if (V < 0 || M <= 0 || q <= 0 || q > 128) return sbm_fail(SBM_E_ARG, "sbm_lm_step: bad sizes V=%d M=%d q=%d (q <= 128)", V, M, q);
+  if (V == 0) return 0;
+  SBM_HIP(hipSetDevice(ctx->device));
+  LmArgs a{J, r, lambda, delta, pred, status, M, q};
+  const size_t ld = (size_t)q + 1;
+  const size_t lds = sizeof(double) * (2 * q * ld + 2 * q + LM_TILE * ld + LM_TILE);
+  if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_lm_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_lm_step, dim3(V), dim3(256), lds, ctx->stream, a);
+  SBM_HIP(hipGetLastError());
+  return 0;
+}

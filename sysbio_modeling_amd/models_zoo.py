@@ -165,7 +165,7 @@ def stiff_ensemble(n_vectors=4096, n=50, seed=20261003, spread=0.25):
 # ----------------------------------------------------------------------------
 # BASELINE.json configs[3]: multi-experiment Project on the cascade model
 # ----------------------------------------------------------------------------
-def cascade_config4_project(model, n_exp=8, seed=7, simulate=None, project_cls=None, **project_kw):
+def cascade_config4_project(model, n_exp=8, seed=7, simulate=None, project_cls=None, noise=0.05, **project_kw):
     """E experiments 'exp_0'..; setting cond = e; d0..d3 each in its own 'Shared' group keyed on cond
     (4 x E slots), the other 36 parameters Global => q = 36 + 4 E (68 at E = 8).  Each experiment:
     species 4/9/14/19 'direct', 16 timepoints linspace(6.25, 100, 16), sigma = 0.05 |data| + 0.01,
@@ -195,7 +195,7 @@ def cascade_config4_project(model, n_exp=8, seed=7, simulate=None, project_cls=N
         y = simulate(p, t_out)[1:]
         ms = []
         for v in CASCADE_MEASURED_SPECIES:
-            data = y[:, v] * (1.0 + 0.05 * rng.standard_normal(len(idx)))
+            data = y[:, v] * (1.0 + noise * rng.standard_normal(len(idx)))
             ms.append(TimecourseMeasurement('s%d' % v, data, CASCADE_MEASURE_TIMES.copy(), 0.05 * np.abs(data) + 0.01))
         exps.append(Experiment('exp_%d' % c, ms, experiment_settings={'cond': c}))
     shared = OrderedDict(('deg%d' % i, {('d%d' % i): ('cond',)}) for i in range(4))

@@ -695,6 +695,12 @@ class Project(object):
                 if np.isfinite(out[v]) else np.inf
         return out
 
+    def fit_batch(self, thetas0, **options):
+        """Multi-start Levenberg-Marquardt from every row of ``thetas0`` at once (project/fitting.py);
+        the batched counterpart of ``leastsq(self.residuals, x0, Dfun=self.calc_project_jacobian)``."""
+        from .fitting import levenberg_marquardt_batch
+        return levenberg_marquardt_batch(self, thetas0, **options)
+
     def nlopt_fcn(self, project_param_vector, grad):
         """nlopt-style objective: fills ``grad`` in place when it is non-empty (reference :829-852)."""
         if grad.size > 0:

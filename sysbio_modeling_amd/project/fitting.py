@@ -1,0 +1,101 @@
+"""Batched multi-start Levenberg-Marquardt on top of the device evaluator.
+
+The reference fits one start at a time: ``scipy.optimize.leastsq(project.residuals, x0,
+Dfun=project.calc_project_jacobian)`` (tests/test_Project.py:202-213, :352-357) -- every function and
+Jacobian evaluation a serial LSODA run per experiment.  Here V starts advance together: one
+``sbm_jacobian_batch`` call integrates all trial points (residuals AND Jacobians from the same augmented
+integration), one ``sbm_lm_step`` call solves the V damped normal equations on the device, and the
+accept / reject bookkeeping is a handful of tensor selects.  Nothing leaves the GPU inside the loop except
+a convergence count per iteration.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+
+
+def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambda_up=4.0, lambda_down=3.0,
+                              ftol=1e-10, xtol=1e-10, max_step=2.0, **integrator_overrides):
+    """Minimise 0.5 |r(theta)|^2 from every row of ``thetas0`` (V, q), independently.
+
+    Marquardt damping per start: a step is accepted when the cost decreases (lambda /= lambda_down),
+    rejected otherwise (lambda *= lambda_up).  A start has converged when a lightly damped (lambda <= 1)
+    accepted step lowers the cost by less than ftol * cost with a predicted decrease just as small, or
+    changes no parameter by more than xtol * (|theta| + xtol).
+    Failed integrations (inf cost) count as rejections.  Two safeguards keep wild trial points from
+    stalling the whole batch (one launch waits for its slowest trajectory): a step is shortened so that no
+    log-parameter moves by more than ``max_step``, and trial integrations get a step budget
+    (``max_steps``, default 20000) -- a trial that exhausts it is simply rejected.
+
+    Returns a dict of numpy arrays: theta (V, q), cost (V,) = 0.5 |r|^2, n_iter (V,) iterations until
+    convergence (max_iter if never), converged (V,) bool, n_evaluations (total trial points integrated).
+    """
+    import torch
+    integrator_overrides.setdefault('max_steps', 20000)
+    if project.reference_compat and project.n_total_rows != project.n_project_residuals:
+        raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
+                         "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
+    lib = _lib.load_library()
+    ctx = _lib.default_context()
+    th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
+    th = th.clone()
+    dev = th.device
+    V, q = th.shape
+    f64, i32 = torch.float64, torch.int32
+    want = ('jacobian',)
+    # reference_compat leaves J undivided by sigma (quirk 3): divide here, the gradient needs d r / d theta
+    inv_sigma = None
+    if project.reference_compat:
+        a = project.descriptor_arrays()
+        inv_sigma = torch.from_numpy(1.0 / a['row_sigma']).to(dev)
+
+    def evaluate(t):
+        out = project.evaluate_batch(t, jacobian=True, want=want, **integrator_overrides)
+        J = out['jacobian']
+        if inv_sigma is not None:
+            J = J * inv_sigma[None, :, None]
+        cost = 0.5 * out['norms']
+        cost = torch.where(torch.isfinite(cost) & (out['status'] == 0), cost, torch.full_like(cost, float('inf')))
+        return out['residuals'], J, cost
+
+    r, J, cost = evaluate(th)
+    M = r.shape[1]
+    lam = torch.full((V,), float(lambda0), dtype=f64, device=dev)
+    delta = torch.empty((V, q), dtype=f64, device=dev)
+    pred = torch.empty((V,), dtype=f64, device=dev)
+    st = torch.empty((V,), dtype=i32, device=dev)
+    done = ~torch.isfinite(cost)                      # a start that cannot be integrated stays where it is
+    n_iter = torch.full((V,), int(max_iter), dtype=torch.int64, device=dev)
+    n_eval = V
+    p = _lib.dev_ptr
+    for it in range(max_iter):
+        # finite stand-ins where the current point is unusable (their steps are discarded below)
+        Jc = torch.where(torch.isfinite(cost)[:, None, None], J, torch.zeros_like(J)).contiguous()
+        rc = torch.where(torch.isfinite(cost)[:, None], r, torch.zeros_like(r)).contiguous()
+        _lib.check(lib.sbm_lm_step(ctx.handle, p(Jc), p(rc), p(lam), V, M, q, p(delta), p(pred), p(st)), 'sbm_lm_step')
+        big = delta.abs().amax(dim=1, keepdim=True)
+        delta = delta * torch.clamp(max_step / big.clamp_min(1e-300), max=1.0)
+        trial = torch.where(done[:, None], th, th + delta)
+        r_t, J_t, cost_t = evaluate(trial)
+        n_eval += V
+        ok = (st == 0) & (cost_t < cost) & ~done
+        # MINPACK-style tests, on lightly damped steps only: a heavily damped step is short whatever the
+        # distance to the optimum
+        free = lam <= 1.0
+        small_f = ok & free & ((cost - cost_t) <= ftol * cost) & (pred <= ftol * cost)
+        small_x = ok & free & (delta.abs() <= xtol * (th.abs() + xtol)).all(dim=1)
+        th = torch.where(ok[:, None], trial, th)
+        r = torch.where(ok[:, None], r_t, r)
+        J = torch.where(ok[:, None, None], J_t, J)
+        cost = torch.where(ok, cost_t, cost)
+        lam = torch.where(ok, lam / lambda_down, lam * lambda_up).clamp(1e-15, 1e15)
+        newly = (small_f | small_x) & ~done
+        n_iter = torch.where(newly, torch.full_like(n_iter, it + 1), n_iter)
+        done = done | newly
+        if bool(done.all()):
+            break
+    return {'theta': th.cpu().numpy(), 'cost': cost.cpu().numpy(), 'n_iter': n_iter.cpu().numpy(),
+            'converged': (done & torch.isfinite(cost)).cpu().numpy(), 'n_evaluations': n_eval}

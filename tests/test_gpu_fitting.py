@@ -1,0 +1,108 @@
+"""Batched multi-start Levenberg-Marquardt against the reference's way of
+fitting: scipy.optimize.leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)
+(tests/test_Project.py:202-213, :352-357), which the same Project object also supports (batch of one)."""
+import ctypes
+import warnings
+
+import numpy as np
+import pytest
+from scipy.optimize import leastsq
+
+from tests import reference_cases as rc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lm_step_solves_damped_normal_equations():
+    """sbm_lm_step against numpy on random systems, including a rank-deficient and a non-finite one."""
+    import torch
+    from sysbio_modeling_amd import _lib
+    rng = np.random.default_rng(0)
+    V, M, q = 7, 45, 11
+    J = rng.standard_normal((V, M, q))
+    r = rng.standard_normal((V, M))
+    lam = 10.0 ** rng.uniform(-6, 2, V)
+    J[3, :, 4] = 0.0                 # a parameter no residual depends on: delta stays 0 there
+    J[5, 2, 1] = np.nan              # unusable input
+    Jd, rd, ld = (torch.from_numpy(x).cuda() for x in (J, r, lam))
+    delta = torch.empty((V, q), dtype=torch.float64, device='cuda')
+    pred = torch.empty((V,), dtype=torch.float64, device='cuda')
+    st = torch.empty((V,), dtype=torch.int32, device='cuda')
+    ctx = _lib.default_context()
+    p = _lib.dev_ptr
+    _lib.check(ctx.lib.sbm_lm_step(ctx.handle, p(Jd), p(rd), p(ld), V, M, q, p(delta), p(pred), p(st)), 'sbm_lm_step')
+    torch.cuda.synchronize()
+    delta, pred, st = delta.cpu().numpy(), pred.cpu().numpy(), st.cpu().numpy()
+    assert st.tolist() == [0, 0, 0, 0, 0, 1, 0] and np.all(delta[5] == 0)
+    for v in (0, 1, 2, 3, 4, 6):
+        A = J[v].T @ J[v]
+        g = J[v].T @ r[v]
+        D = np.diag(np.where(np.diag(A) > 0, np.diag(A) * (1 + lam[v]), 1.0))
+        ref = np.linalg.solve(A - np.diag(np.diag(A)) + D, -g)
+        assert np.allclose(delta[v], ref, rtol=1e-9, atol=1e-12)
+        assert pred[v] == pytest.approx(-(g @ ref) - 0.5 * ref @ A @ ref, rel=1e-9)
+    assert delta[3, 4] == 0.0
+
+
+def _exact_simple_project(m, theta_true, sf_groups=None):
+    """Two experiments of the one-state model (shared k_synt, one k_deg each: the structure of
+    tests/test_Project.py:27-72) with data the model itself produces at ``theta_true``."""
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    t = np.linspace(5.0, 100.0, 20)
+    grid = np.linspace(0, 100.0, 1000)
+    t_on_grid = grid[np.searchsorted(grid, t)]
+    exps = []
+    for name, kd in (('Low', theta_true[1]), ('High', theta_true[0])):
+        y = m.simulate(np.exp([kd, theta_true[2]]), np.concatenate([[0.0], t_on_grid]))[1:, 0]
+        exps.append(Experiment('%s_Deg_Exp' % name, TimecourseMeasurement('Variable_1', y, t),
+                               experiment_settings={'Deg_Rate': name}))
+    settings = {'Global': ['k_synt'], 'Shared': {'Group_1': {'k_deg': ('Deg_Rate',)}}}
+    return Project(m, exps, settings, {'Variable_1': ('direct', 0)}, sf_groups=sf_groups, reference_compat=False)
+
+
+def test_multi_start_fit_matches_leastsq(gpu_models):
+    """The reference fits with leastsq(proj.residuals, x0, Dfun=proj.calc_project_jacobian)
+    (tests/test_Project.py:202-213).  Same call through this package's Project (batch of one), and 64
+    starts at once with fit_batch: all reach the parameters that generated the data."""
+    m = gpu_models('simple')
+    proj = _exact_simple_project(m, np.log([0.05, 0.02, 0.3]))
+    truth = np.zeros(3)
+    truth[proj.get_param_index('Group_1', ('High',))] = np.log(0.05)
+    truth[proj.get_param_index('Group_1', ('Low',))] = np.log(0.02)
+    truth[proj.get_param_index('k_synt', 'Global')] = np.log(0.3)
+    assert proj.calc_sum_square_residuals(truth) < 1e-16
+    x0 = truth + np.array([0.4, -0.3, 0.5])
+    x_ref, _, info, _, ier = leastsq(proj.residuals, x0, Dfun=proj.calc_project_jacobian, full_output=True)
+    assert ier in (1, 2, 3, 4) and np.allclose(x_ref, truth, atol=1e-6)
+    rng = np.random.default_rng(5)
+    starts = truth[None, :] + rng.uniform(-1.0, 1.0, (64, 3))
+    starts[0] = x0
+    fit = proj.fit_batch(starts, max_iter=60)
+    assert fit['converged'].all()
+    assert np.allclose(fit['theta'], truth[None, :], atol=1e-6)
+    assert fit['cost'].max() < 1e-14
+    # one batched evaluation per iteration: far fewer launches than 64 serial fits
+    assert fit['n_evaluations'] <= 64 * 61 and fit['n_iter'].max() <= 40
+    assert info['nfev'] >= 4          # leastsq needed several serial evaluations for ONE start
+
+
+def test_fit_batch_on_the_config4_project(gpu_models):
+    """configs[3]-style project (8 experiments, 512 rows, 68 parameters, 4 free scale factors) with
+    noise-free data: a sloppy problem (rate constants and scale factors trade off), so the test is on the
+    cost, not on the parameters: 32 starts scattered around the truth, 40 iterations = 41 batched
+    evaluations of 256 trajectories each."""
+    from sysbio_modeling_amd import models_zoo
+    m = gpu_models('cascade20')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        proj, th0 = models_zoo.cascade_config4_project(m, noise=0.0, reference_compat=False)
+        assert proj.calc_sum_square_residuals(th0) < 1e-12
+        starts = th0[None, :] + 0.15 * np.random.default_rng(1).standard_normal((32, th0.size))
+        c0 = proj.calc_sum_square_residuals_batch(starts)
+        fit = proj.fit_batch(starts, max_iter=40)
+    assert fit['n_evaluations'] == 32 * 41
+    assert np.all(fit['cost'] <= c0)
+    assert np.median(fit['cost']) < 1e-5 * np.median(c0)
+    assert (fit['cost'] < 1e-3 * c0).sum() >= 28
