@@ -106,3 +106,41 @@ def test_fit_batch_on_the_config4_project(gpu_models):
     assert np.all(fit['cost'] <= c0)
     assert np.median(fit['cost']) < 1e-5 * np.median(c0)
     assert (fit['cost'] < 1e-3 * c0).sum() >= 28
+
+
+def test_multi_chain_sampler_reproduces_the_gaussian_posterior(gpu_models):
+    """ensemble_log_params_batch (reference Ensembles.py:55-178, C chains at once).  Noise-free data with
+    1 % error bars: the posterior is the Gaussian N(theta*, (J^T J)^-1) to a good approximation, so the
+    pooled chains must reproduce its mean and standard deviations; the acceptance ratio of the reference's
+    candidate density (expected quadratic cost increase ~ 1) sits around one half."""
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    from sysbio_modeling_amd.project.ensembles import ensemble_log_params_batch, sampling_matrix
+    m = gpu_models('simple')
+    truth_p = np.array([0.05, 0.3])            # k_deg, k_synt
+    t = np.linspace(5.0, 100.0, 20)
+    grid = np.linspace(0, 100.0, 1000)
+    y = m.simulate(truth_p, np.concatenate([[0.0], grid[np.searchsorted(grid, t)]]))[1:, 0]
+    exp = Experiment('E', TimecourseMeasurement('Variable_1', y, t, 0.01 * y))
+    proj = Project(m, [exp], {'Global': ['k_deg', 'k_synt']}, {'Variable_1': ('direct', 0)}, reference_compat=False)
+    truth = np.zeros(2)
+    truth[proj.get_param_index('k_deg', 'Global')] = np.log(0.05)
+    truth[proj.get_param_index('k_synt', 'Global')] = np.log(0.3)
+    J = proj.calc_project_jacobian(truth)
+    cov = np.linalg.inv(J.T @ J)
+    # the candidate density: samp samp^T = (0.5 H)^-1 / q
+    samp = sampling_matrix(J.T @ J)
+    assert np.allclose(samp @ samp.T, np.linalg.inv(0.5 * J.T @ J) / 2, rtol=1e-9)
+    ens, ens_F, ratio = ensemble_log_params_batch(proj, np.tile(truth, (128, 1)), steps=400, seeds=11)
+    assert ens.shape == (401, 128, 2) and ens_F.shape == (401, 128) and ratio.shape == (128,)
+    assert 0.3 < ratio.mean() < 0.75
+    assert np.all(ens_F[0] < 1e-12) and np.all(ens_F >= 0)
+    pooled = ens[100:].reshape(-1, 2)
+    sd = np.sqrt(np.diag(cov))
+    assert np.all(np.abs(pooled.mean(axis=0) - truth) < 0.1 * sd)
+    assert np.allclose(pooled.std(axis=0), sd, rtol=0.15)
+    assert np.corrcoef(pooled.T)[0, 1] == pytest.approx(cov[0, 1] / (sd[0] * sd[1]), abs=0.1)
+    # skip_elems thins the record, not the walk
+    ens2, _, _ = ensemble_log_params_batch(proj, truth, steps=50, seeds=3, skip_elems=4)
+    assert ens2.shape == (11, 1, 2)
