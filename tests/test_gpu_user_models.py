@@ -1,0 +1,96 @@
+"""User models end to end on the GPU box: model text -> SymPy -> generated HIP -> hipcc at run time
+-> plugin -> kernels, against SciPy odeint on the generated Python callables (the reference's own
+pipeline is parse -> process -> make_ode_model -> exec, symbolic/sympy_tools.py:162-397).  Nothing here
+is a committed header: these are the code paths a user's own model takes."""
+import numpy as np
+import pytest
+
+from tests.conftest import parity_err
+
+pytestmark = pytest.mark.gpu
+
+# a small signalling motif with a conservation law, rate laws and a fixed parameter
+MOTIF_TEXT = """
+#*! Parameters Start
+    k_on = p[0]
+    k_off = p[1]
+    k_cat = p[2]
+    k_deg = p[3]
+    e_tot = p[4]
+#*! Parameters End
+
+#*! Variables Start
+    _c = y[0]
+    _p = y[1]
+    _q = y[2]
+#*! Variables End
+
+#*! Conservation Laws Start
+    _e = e_tot - _c
+#*! Conservation Laws End
+
+#*! Rate Laws Start
+    v_bind = k_on * _e * (1.0 / (1.0 + _p))
+    v_cat = k_cat * _c
+#*! Rate Laws End
+
+#*! Differential Equations Start
+    d__c = v_bind - k_off * _c - v_cat
+    d__p = v_cat - k_deg * _p
+    d__q = k_deg * _p - 0.05 * _q
+#*! Differential Equations End
+"""
+
+
+def _odeint_ref(gm, p, t):
+    from oracle import odeint_oracle as oo
+    return oo.simulate(gm, p, t), oo.calc_jacobian(gm, p, t)
+
+
+def test_model_text_with_laws_and_fixed_parameter(tmp_path):
+    """Conservation law + rate laws substituted, one parameter 'fixed' (no sensitivity column: the
+    compact column index of SURVEY.md section 8a, quirk 6); every kernel variant the model supports."""
+    from sysbio_modeling_amd.symbolic import make_ode_model
+    from sysbio_modeling_amd.model import OdeModel
+    gm = make_ode_model(MOTIF_TEXT, name='motif', fixed_params=['e_tot'])
+    assert gm.n_vars == 3 and len(gm.param_order) == 5 and gm.n_sens == 4
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='motif')
+    rng = np.random.default_rng(4)
+    P = np.array([0.8, 0.2, 0.5, 0.1, 1.5]) * np.exp(0.3 * rng.standard_normal((5, 5)))
+    t = np.linspace(0, 30.0, 1000)
+    idx = np.arange(0, 1000, 111)
+    for variant in ('per_wave', 'row_lane', 'row_group', 'auto'):
+        S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant)
+        assert m.last_info['status'].tolist() == [0] * 5 and S.shape == (5, len(idx), 3 * 4)
+        for v in (0, 4):
+            Yr, Sr = _odeint_ref(gm, P[v], t)
+            assert parity_err(Y[v], Yr[idx]) <= 1.0 and parity_err(S[v], Sr[idx]) <= 1.0
+    Y = m.simulate_batch(P, t[idx])
+    assert parity_err(Y[0], _odeint_ref(gm, P[0], t)[0][idx]) <= 1.0
+    # stiff-capable path on the same model
+    S2 = m.calc_jacobian_batch(P[:2], t[idx], method='implicit_midpoint', n_steps=4096, extrapolate=1,
+                               rtol=1e-11, atol=1e-13)
+    assert parity_err(S2[0], _odeint_ref(gm, P[0], t)[1][idx]) <= 1.0
+
+
+def test_more_sensitivity_columns_than_lanes():
+    """35 species, 70 parameters: 71 columns of [y | S] do not fit 64 lanes, so the per-wave kernel
+    runs two columns per lane (CPL = 2) and the row-lane / row-group forms do not apply."""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    from sysbio_modeling_amd.model import OdeModel
+    gm = GeneratedModel(models_zoo.cascade_spec(35, name='cascade35'))
+    assert gm.n_sens == 70
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='cascade35')
+    rng = np.random.default_rng(9)
+    P = models_zoo.cascade_nominal_params(35)[None, :] * np.exp(0.3 * rng.standard_normal((3, 70)))
+    t = np.linspace(0, 60.0, 1000)
+    idx = np.array([0, 300, 999])
+    S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True)
+    assert m.last_info['status'].tolist() == [0, 0, 0]
+    Yr, Sr = _odeint_ref(gm, P[1], t)
+    assert parity_err(Y[1], Yr[idx]) <= 1.0 and parity_err(S[1], Sr[idx]) <= 1.0
+    S_rk = m.calc_jacobian_batch(P, t[idx], method='rk4', n_steps=8192)
+    assert np.allclose(S_rk, S, rtol=1e-7, atol=1e-9)
+    with pytest.raises(Exception):
+        m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=64)   # needs n_sens <= 64
