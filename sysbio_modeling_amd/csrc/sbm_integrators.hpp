@@ -808,6 +808,103 @@ __global__ void __launch_bounds__(64) sbm_sens_rowlane_kernel(sbm_kernel_args a)
 }
 
 // ===========================================================================
+// State-only kernel, one trajectory per wavefront: lane i integrates y_i and evaluates f_i with the
+// class bodies of the row-lane form.  The lane-per-trajectory kernel above needs 64 trajectories to
+// fill ONE wave: an ensemble of 4096 is 64 waves on a chip with 1024 SIMDs, and the launch takes as
+// long as one trajectory's serial chain of ~1400-instruction steps.  Here the same ensemble is 4096
+// small waves (a handful of registers each, 8 per SIMD) of ~400-instruction steps.  Past ~64k
+// trajectories the chip is full either way and the lane-per-trajectory kernel, which does no
+// redundant work, wins again (launcher).
+// ===========================================================================
+template <class M>
+struct StateRowSystem {
+  static constexpr int NV = 0;           // no column rows: the lane's state component is the "extra" element
+  static constexpr int NVX = 1;
+  static constexpr int CPL = 1;
+  static constexpr int NCS = 1;
+  static constexpr bool kUniform = true;
+  __device__ __forceinline__ static constexpr int col_of(int, int) { return 0; }
+  double* Y;                     // [64] in LDS: stage state, one component per lane
+  int lane, cls;
+  int yidx[M::RL_MAXYS];
+  double ps[M::RL_MAXPS];
+
+  struct Pending { double ys[M::RL_MAXYS]; };
+  struct Token { double f; };
+  __device__ __forceinline__ Pending issue(double, const double (&z)[1][1]) const {
+    Pending p;
+    Y[lane] = z[0][0];
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[s] = Y[yidx[s]];
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    return p;
+  }
+  __device__ __forceinline__ Token eval(const Pending& p, double t) const {
+    Token k;
+    double jy[M::RL_MAXJY], jp[M::RL_MAXJP];   // dead: the compiler drops the Jacobian arithmetic
+    k.f = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
+    M::class_dispatch(cls, t, p.ys, ps, k.f, jy, jp);
+    k.f = cls >= 0 ? k.f : 0.0;
+    return k;
+  }
+  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][1]) const { dz[0][0] = k.f; }
+  __device__ __forceinline__ void finish(const Token&, double, const double (&)[1][1], double (&)[1][1]) const {}
+  __device__ __forceinline__ void rhs(double t, const double (&z)[1][1], double (&dz)[1][1]) const {
+    extra_out(eval(issue(t, z), t), dz);
+  }
+  __device__ __forceinline__ float norm(const float (&)[1], float xsum) const {
+    const float x = (lane < M::NV) ? sbm_nan_to_inf(xsum) : 0.f;
+    return sqrtf(sbm_wave_sumf(x) * (1.0f / M::NV));
+  }
+  __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
+};
+
+template <class M, int METHOD>
+__global__ void __launch_bounds__(64) sbm_state_rows_kernel(sbm_kernel_args a) {
+  using Sys = StateRowSystem<M>;
+  static_assert(M::NV <= 64, "one state component per lane");
+  __shared__ double Ysh[64];
+  if ((int)blockIdx.x >= a.n_traj) return;
+  const int traj = blockIdx.x;
+  const int lane = threadIdx.x;
+  Ysh[lane] = 0.0;
+  Sys sys;
+  sys.Y = Ysh;
+  sys.lane = lane;
+  const bool has_row = lane < M::NV;
+  const int row = has_row ? lane : 0;
+  sys.cls = has_row ? M::rl_class(row) : -1;
+  const double* P = a.P + (size_t)traj * M::NP;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[s] = M::rl_ys(s, row);
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[s] = P[M::rl_ps(s, row)];
+  __syncthreads();
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+  double z[1][1];
+  z[0][0] = (a.y0 && has_row) ? a.y0[lane] : 0.0;
+  double* Yt = a.Y + (size_t)traj * a.n_t * M::NV;
+  auto store = [&](int io, const double (&zz)[1][1]) {
+    if (has_row) Yt[(size_t)io * M::NV + lane] = zz[0][0];
+  };
+  SbmTrajOut r;
+  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
+  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+  if (lane == 0) {
+    if (a.status) a.status[traj] = r.status;
+    if (a.n_steps) a.n_steps[traj] = r.n_acc;
+    if (a.n_reject) a.n_reject[traj] = r.n_rej;
+  }
+}
+
+// ===========================================================================
 // Row-group sensitivity kernel: the row-lane kernel with the rows of a column split over G lanes.
 //
 // One trajectory per wavefront, as before; the state still lives one component per lane and the
@@ -1262,6 +1359,18 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
   } else {
+    // one trajectory per wave until the chip is full of lane-per-trajectory waves anyway
+    constexpr bool kRowsOk = (M::NV <= 64) && (M::RL_NCLASS * 4 <= M::NV + 3);
+    if constexpr (kRowsOk) {
+      if (a.n_traj < 65536 && a.opts.variant != SBM_VARIANT_PER_WAVE) {
+        dim3 grid(a.n_traj), block(64);
+        if (a.opts.method == SBM_DOPRI45)
+          hipLaunchKernelGGL((sbm_state_rows_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+        else
+          hipLaunchKernelGGL((sbm_state_rows_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+        return (int)hipGetLastError();
+      }
+    }
     dim3 grid((a.n_traj + 63) / 64), block(64);
     if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_state_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((sbm_state_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
