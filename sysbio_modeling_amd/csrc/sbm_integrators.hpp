@@ -44,6 +44,9 @@ __device__ __forceinline__ double sbm_rcp(double x) {
   return r;
 }
 #define SBM_RCP(x) sbm_rcp(x)
+// compiler-level ordering point for memory operations (no instruction): generated code uses it to bound
+// how far loads are hoisted
+#define SBM_LDS_FENCE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
 
 // J_p[row, scol] picked per lane.  Arguments BY VALUE: the candidates are computed
 // unconditionally and this lowers to v_cndmask -- written as a ?: chain over array
@@ -1142,6 +1145,24 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   }
 }
 
+// v[lane] of a per-lane array held in registers: a binary select tree over the bits of `lane`.  The
+// obvious chain of `lane == i` selects makes the compiler keep N loop-invariant 64-bit lane masks in
+// SGPRs (100 of them for N = 50: it spilled them through v_writelane and AGPRs); the tree needs
+// log2(N) masks for the same number of selects.
+template <int N, int BIT = 0>
+__device__ __forceinline__ double sbm_pick_tree(const double (&v)[N], int lane) {
+  if constexpr (N == 1) {
+    return v[0];
+  } else {
+    constexpr int H = (N + 1) / 2;
+    double t[H];
+    const bool odd = ((lane >> BIT) & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) t[j] = (2 * j + 1 < N) ? sbm_sel(odd, v[2 * j + 1 < N ? 2 * j + 1 : 0], v[2 * j]) : v[2 * j];
+    return sbm_pick_tree<H, BIT + 1>(t, lane);
+  }
+}
+
 // ===========================================================================
 // Implicit midpoint for stiff systems (BASELINE configs[4]), state + forward sensitivities.
 //
@@ -1166,8 +1187,12 @@ struct SbmImidShared {
   double G[64];                 // Newton residual, one component per row lane
   double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
   double A[M::NV * 64 + 2];     // A[i][c] = J_p[i][c] (+ spare slot)
+  double MF[M::IM_NM + 2];      // IM_TRI: reciprocal pivots and scaled entries, written row by row lane
 };
 
+// Lower-triangular J_y (feed-forward networks, M::IM_TRI): no elimination is needed, so the "factorisation"
+// is one reciprocal per ROW and runs distributed -- row lane i scales its own row and publishes it in MF --
+// instead of n reciprocals on every lane; the forward substitution then reads MF (wave-uniform).
 template <class M>
 __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   constexpr int NV = M::NV, NK = M::NK;
@@ -1179,6 +1204,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   const int lane = threadIdx.x;
   for (int i = lane; i < NV * 64 + 2; i += 64) sh.A[i] = 0.0;
   for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
+  for (int i = lane; i < M::IM_NM + 2; i += 64) sh.MF[i] = 0.0;
   sh.Y[lane] = 0.0;
   sh.G[lane] = 0.0;
 
@@ -1197,6 +1223,11 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   for (int s = 0; s < M::RL_MAXJY; ++s) jyout[s] = has_row ? M::rl_jyout(s, row) : M::NJY + 1;
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJP; ++s) apos[s] = has_row ? M::rl_apos(s, row) : NV * 64 + 1;
+  int mfpos[M::RL_MAXJY];
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJY; ++s) mfpos[s] = (M::IM_TRI && has_row) ? M::im_mfpos(s, row) : M::IM_NM + 1;
+  const int rdpos = (M::IM_TRI && has_row) ? M::im_rstart(row) : M::IM_NM + 1;
+  const int diagslot = (M::IM_TRI && has_row) ? M::im_diagslot(row) : -1;
   __syncthreads();
 
   const int goff = a.grid_off ? a.grid_off[traj] : 0;
@@ -1256,17 +1287,31 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
 #pragma unroll
             for (int q = 0; q < M::RL_MAXJY; ++q) sh.JY[jyout[q]] = jy[q];
             sh.G[lane] = has_row ? (yb - y) - hh * f : 0.0;
+            if constexpr (M::IM_TRI) {
+              double jd = 0.0;
+#pragma unroll
+              for (int q = 0; q < M::RL_MAXJY; ++q) jd = sbm_sel(diagslot == q, jy[q], jd);
+              const double rd = sbm_rcp(fma(-hh, jd, 1.0));
+              sh.MF[rdpos] = rd;
+#pragma unroll
+              for (int q = 0; q < M::RL_MAXJY; ++q) sh.MF[mfpos[q]] = hh * jy[q] * rd;
+            }
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            M::im_build(hh, sh.JY, m);
-            M::im_factor(m);
             double b[NV];
+            if constexpr (M::IM_TRI) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) b[i] = sh.G[i];
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            M::im_solve(m, b);
-            double d = 0.0;
+              for (int i = 0; i < NV; ++i) b[i] = sh.G[i];
+              M::im_solve_tri(sh.MF, b);
+              __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            } else {
+              M::im_build(hh, sh.JY, m);
+              M::im_factor(m);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) d = sbm_sel(lane == i, b[i], d);
+              for (int i = 0; i < NV; ++i) b[i] = sh.G[i];
+              __atomic_signal_fence(__ATOMIC_SEQ_CST);
+              M::im_solve(m, b);
+            }
+            const double d = has_row ? sbm_pick_tree<NV>(b, lane) : 0.0;   // lane i keeps delta_i
             yb -= d;
             float r = has_row ? (float)(fabs(d) / fma(rtol, fabs(yb), atol)) : 0.f;
             r = sbm_wave_max(sbm_nan_to_inf(r));
@@ -1282,8 +1327,9 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
             double b[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) b[i] = fma(hh, sh.A[i * 64 + lane], z[i]);
+            if constexpr (M::IM_TRI) M::im_solve_tri(sh.MF, b);
+            else M::im_solve(m, b);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            M::im_solve(m, b);
 #pragma unroll
             for (int i = 0; i < NV; ++i) z[i] = fma(2.0, b[i], -z[i]);
           }

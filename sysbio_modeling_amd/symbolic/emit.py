@@ -337,7 +337,9 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     L = _fmt_header(spec, "//")
     rl_tables, rl_meta = emit_rowlane.emit_rowlane_tables(spec, d, None)
     rg_tables, rg_layout = emit_rowgroup.emit_tables(spec, d)
-    L += ["#pragma once", ""] + rl_tables + rg_tables + [
+    im_members, im_meta = emit_implicit.emit_members(spec, d)
+    im_tables = emit_implicit.emit_tables(spec, d, im_meta)
+    L += ["#pragma once", ""] + rl_tables + rg_tables + im_tables + [
           "struct SbmModel {",
           "  static constexpr int NV = %d;      // state variables" % n,
           "  static constexpr int NP = %d;      // model parameters (length of p)" % spec.n_params,
@@ -426,6 +428,9 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     L += emit_rowlane.emit_rowlane_members(spec, d, rl_meta,
                                            lambda smap: _ExprPrinter(smap, rcp="SBM_RCP(%s)", lang='hip'))
     L += [""] + emit_rowgroup.emit_members(spec, d, rg_layout)
-    L += [""] + emit_implicit.emit_members(spec, d)
+    L += [""] + im_members + [
+        "  __device__ __forceinline__ static int im_rstart(int row) { return SBM_IM_RSTART[IM_TRI ? row : 0]; }",
+        "  __device__ __forceinline__ static int im_diagslot(int row) { return SBM_IM_DIAGSLOT[IM_TRI ? row : 0]; }",
+        "  __device__ __forceinline__ static int im_mfpos(int slot, int row) { return SBM_IM_MFPOS[IM_TRI ? slot * NV + row : 0]; }"]
     L += ["};", ""]
     return "\n".join(L)

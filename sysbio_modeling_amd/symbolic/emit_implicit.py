@@ -14,6 +14,12 @@ included -- and printed as straight-line code with static indices:
 For a cascade (J_y lower bidiagonal) this is 2n-1 entries, no fill and no backward pass; a dense
 n x n solve would be n^3/3 flops per factorisation.  Every lane of a wavefront runs the same code
 on the same (wave-uniform) matrix and its own right-hand side (one sensitivity column each).
+
+Lower-triangular patterns (feed-forward networks) need no elimination at all: the pivots are the
+diagonal entries.  For them the emitter adds a DISTRIBUTED form (IM_TRI): row lane i, which has just
+evaluated row i of J_y, computes its own reciprocal pivot and scaled off-diagonal entries -- one
+reciprocal per lane instead of n per lane -- and publishes them in the table MF; ``im_solve_tri``
+then is the forward substitution reading MF (wave-uniform LDS reads).
 """
 from __future__ import annotations
 
@@ -84,4 +90,56 @@ def emit_members(spec, d):
                 L.append("    b[%d] = fma(-m[%d], b[%d], b[%d]);" % (i, idx[(r, c)], c, i))
         L.append("    b[%d] *= m[%d];" % (i, idx[(i, i)]))
     L += ["  }"]
-    return L
+    # ---- distributed form for lower-triangular patterns ----
+    L += ["  static constexpr bool IM_TRI = %s;" % ("true" if lower_only else "false")]
+    if lower_only:
+        rstart, pos = [], {}
+        k = 0
+        for i in range(n):
+            rstart.append(k)
+            k += 1
+            for (r, c) in pattern:
+                if r == i and c < i:
+                    pos[(r, c)] = k
+                    k += 1
+        assert k == nm
+        L += ["  // MF layout: per row [1/M_ii, then gamma*J_ij/M_ii for j < i in column order]; b <- M^-1 b",
+              "  __device__ __forceinline__ static void im_solve_tri(const double* mf, double (&b)[NV]) {"]
+        for i in range(n):
+            expr = "mf[%d] * b[%d]" % (rstart[i], i)
+            for (r, c) in pattern:
+                if r == i and c < i:
+                    expr = "fma(mf[%d], b[%d], %s)" % (pos[(r, c)], c, expr)
+            L.append("    b[%d] = %s;" % (i, expr))
+            if i % 8 == 7 and i + 1 < n:
+                # keep the compiler from hoisting every table load to the top (2*IM_NM live registers)
+                L.append("    SBM_LDS_FENCE();")
+        L += ["  }"]
+        return L, dict(tri=True, rstart=rstart, pos=pos, nm=nm)
+    L += ["  __device__ __forceinline__ static void im_solve_tri(const double*, double (&)[NV]) {}"]
+    return L, dict(tri=False, nm=nm)
+
+
+def emit_tables(spec, d, meta):
+    """Namespace-scope tables of the distributed triangular form: where row lane i puts its reciprocal
+    pivot (IM_RSTART[row]) and class slot s of its row (IM_MFPOS[slot][row]; IM_NM = nowhere), and which
+    slot holds the diagonal entry (IM_DIAGSLOT[row], -1: none)."""
+    n = spec.n_vars
+    max_jy = max([len(x) for x in d.jy_rows] + [1])
+    if not meta['tri']:
+        return ["__constant__ short SBM_IM_RSTART[1] = {0};", "__constant__ short SBM_IM_DIAGSLOT[1] = {-1};",
+                "__constant__ short SBM_IM_MFPOS[1] = {0};", ""]
+    nm = meta['nm']
+    diag = [-1] * n
+    mfpos = [[nm] * n for _ in range(max_jy)]
+    for i in range(n):
+        for sidx, (e_idx, c) in enumerate(d.jy_rows[i]):
+            if c == i:
+                diag[i] = sidx
+            else:
+                mfpos[sidx][i] = meta['pos'][(i, c)]
+    return ["// distributed triangular solve (emit_implicit.py)",
+            "__constant__ short SBM_IM_RSTART[%d] = {%s};" % (n, ", ".join(str(v) for v in meta['rstart'])),
+            "__constant__ short SBM_IM_DIAGSLOT[%d] = {%s};" % (n, ", ".join(str(v) for v in diag)),
+            "__constant__ short SBM_IM_MFPOS[%d] = {%s};" % (max_jy * n, ", ".join(str(v) for sl in mfpos for v in sl)),
+            ""]

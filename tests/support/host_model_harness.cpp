@@ -12,6 +12,7 @@
 #define __constant__ static const
 #define __forceinline__ inline
 #define SBM_RCP(x) (1.0 / (x))
+#define SBM_LDS_FENCE() ((void)0)
 #define SBM_PICK(scol, c, v, otherwise) ((scol) == (c) ? (v) : (otherwise))
 #define SBM_SEL(c, a, b) ((c) ? (a) : (b))
 // On the device SBM_LANE_BCAST(jy[slot], lane) reads register jy[slot] of another lane.  Here the
@@ -170,5 +171,36 @@ void h_im_solve(double gamma, const double* y, double t, const double* p, double
   M::im_factor(m);
   M::im_solve(m, bb);
   for (int i = 0; i < M::NV; ++i) b[i] = bb[i];
+}
+
+// The distributed triangular form (IM_TRI): every row scales itself (what row lane i does in the
+// kernel), then the forward substitution reads the table.  Returns -1 when the model has no such form.
+int h_im_solve_tri(double gamma, const double* y, double t, const double* p, double* b) {
+  using M = SbmModel;
+  if constexpr (!M::IM_TRI) {
+    (void)gamma; (void)y; (void)t; (void)p; (void)b;
+    return -1;
+  } else {
+    static double MF[M::IM_NM + 2];
+    for (double& v : MF) v = 0.0;
+    for (int row = 0; row < M::NV; ++row) {
+      double ys[M::RL_MAXYS], ps[M::RL_MAXPS], f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+      for (int s = 0; s < M::RL_MAXYS; ++s) ys[s] = y[M::rl_ys(s, row)];
+      for (int s = 0; s < M::RL_MAXPS; ++s) ps[s] = p[M::rl_ps(s, row)];
+      for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+      for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
+      M::class_dispatch(M::rl_class(row), t, ys, ps, f, jy, jp);
+      double jd = 0.0;
+      for (int s = 0; s < M::RL_MAXJY; ++s) if (M::im_diagslot(row) == s) jd = jy[s];
+      const double rd = 1.0 / (1.0 - gamma * jd);
+      MF[M::im_rstart(row)] = rd;
+      for (int s = 0; s < M::RL_MAXJY; ++s) MF[M::im_mfpos(s, row)] = gamma * jy[s] * rd;
+    }
+    double bb[M::NV];
+    for (int i = 0; i < M::NV; ++i) bb[i] = b[i];
+    M::im_solve_tri(MF, bb);
+    for (int i = 0; i < M::NV; ++i) b[i] = bb[i];
+    return 0;
+  }
 }
 }

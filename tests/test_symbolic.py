@@ -273,6 +273,13 @@ def test_generated_sparse_lu_solves_newton_matrix(name, tmp_path):
                        x.ctypes.data_as(dp))
         ref = np.linalg.solve(np.eye(n) - gamma * J, b)
         assert np.allclose(x, ref, rtol=1e-6, atol=1e-8)
+        # distributed form of lower-triangular patterns (feed-forward models)
+        x2 = b.copy()
+        rc_ = lib.h_im_solve_tri(ctypes.c_double(gamma), y.ctypes.data_as(dp), ctypes.c_double(0.0),
+                                 p.ctypes.data_as(dp), x2.ctypes.data_as(dp))
+        assert rc_ == (0 if name in ('simple', 'michaelis_menten', 'stiff50') else -1)
+        if rc_ == 0:
+            assert np.allclose(x2, x, rtol=1e-12, atol=1e-14)
 
 
 def test_symbolic_lu_fill_in():
