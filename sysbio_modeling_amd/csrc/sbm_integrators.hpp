@@ -1047,8 +1047,11 @@ struct RowGroupSystem {
 };
 
 template <class M, int METHOD>
+// Two waves per SIMD (256 registers each) when the lane's share of S is small enough for DOPRI45's seven
+// stage vectors to fit: 2*(RPG*CPL + 1)*7 + operands <= 256 holds up to 15 elements (cascade20: 14 + 1).
+// Larger shares get the whole register file (one wave per SIMD) rather than spill.
 #ifndef SBM_RG_MIN_WAVES
-#define SBM_RG_MIN_WAVES 2
+#define SBM_RG_MIN_WAVES ((M::RG_RPG * M::RG_CPL + 1 <= 15 || METHOD == SBM_RK4_FIXED) ? 2 : 1)
 #endif
 __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel(sbm_kernel_args a) {
   using Sys = RowGroupSystem<M, METHOD == SBM_RK4_FIXED>;
