@@ -293,6 +293,16 @@ int sbm_lm_step(sbm_ctx* ctx, const double* J_dev, const double* r_dev, const do
                 int32_t V, int32_t M, int32_t q, double* delta_dev, double* pred_dev,
                 int32_t* status_dev);
 
+/* ---- multi-GPU: the one exchange of the path ----------------------------- */
+/* The path shards by parameter vector with no data-path collective; what every
+ * rank may want afterwards is everybody's per-vector ||r||^2 (sbm_residuals_batch's
+ * `norms`).  nccl_comm: an ncclComm_t of RCCL created by the caller (one rank per
+ * GPU); send [count] and recv [n_ranks * count] are device buffers; enqueued on the
+ * context's stream.  RCCL is looked up in the running process (no link dependency).
+ * Python hosts use torch.distributed instead (sysbio_modeling_amd/distributed.py). */
+int sbm_allgather_norms(sbm_ctx* ctx, void* nccl_comm, const double* send_dev, int32_t count,
+                        double* recv_dev);
+
 #ifdef __cplusplus
 }
 #endif

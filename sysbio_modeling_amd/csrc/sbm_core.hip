@@ -1150,3 +1150,31 @@ extern "C" int sbm_lm_step(sbm_ctx* ctx, const double* J, const double* r, const
   SBM_HIP(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The one collective of the path: all-gather of the per-vector residual norms.
+// RCCL is resolved at run time from whatever instance the process already has loaded -- the one that
+// created the caller's communicator -- so that libsbm_hip.so neither links RCCL nor brings a second copy
+// into a process whose host framework ships its own.
+// ---------------------------------------------------------------------------------------------
+typedef int (*sbm_nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+
+extern "C" int sbm_allgather_norms(sbm_ctx* ctx, void* nccl_comm, const double* send, int32_t count, double* recv) {
+  if (!ctx || !nccl_comm || !send || !recv) return sbm_fail(SBM_E_ARG, "sbm_allgather_norms: NULL argument");
+  if (count < 0) return sbm_fail(SBM_E_ARG, "sbm_allgather_norms: count < 0");
+  if (count == 0) return 0;
+  static sbm_nccl_allgather_fn fn = nullptr;
+  if (!fn) {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);      // already in the process?
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);    // no: load the system one
+    if (!h) return sbm_fail(SBM_E_PLUGIN, "sbm_allgather_norms: RCCL not found: %s", dlerror());
+    fn = (sbm_nccl_allgather_fn)dlsym(h, "ncclAllGather");
+    if (!fn) return sbm_fail(SBM_E_PLUGIN, "sbm_allgather_norms: ncclAllGather not found in RCCL");
+  }
+  SBM_HIP(hipSetDevice(ctx->device));
+  const int nccl_double = 8;   // ncclFloat64 (rccl.h)
+  const int rc = fn(send, recv, (size_t)count, nccl_double, nccl_comm, ctx->stream);
+  if (rc != 0) return sbm_fail(SBM_E_HIP, "sbm_allgather_norms: ncclAllGather returned %d", rc);
+  return 0;
+}

@@ -683,3 +683,34 @@ def test_free_energy_and_scale_factor_entropy(gpu_models, zoo):
         assert fe == pytest.approx(ref, rel=1e-7)
     fb = proj.free_energy_batch(np.stack([theta, theta + 0.1]), 1.0)
     assert fb[0] == pytest.approx(proj.free_energy(theta, 1.0), rel=1e-12) and np.isfinite(fb[1])
+
+
+def test_c_abi_allgather_norms_single_rank():
+    """sbm_allgather_norms with a communicator the HOST creates through RCCL's own C API (as a non-Python
+    host would): one rank here -- the gather of 1 rank is a copy, but the call goes through RCCL on the
+    context's stream.  The multi-rank sharding logic is covered on CPU (tests/test_distributed_cpu.py)."""
+    import ctypes
+    import torch
+    from sysbio_modeling_amd import _lib
+    torch.zeros(1, device='cuda')
+    rccl = ctypes.CDLL('librccl.so.1')
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [('internal', ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        ctx = _lib.default_context()
+        send = torch.arange(1000, dtype=torch.float64, device='cuda') * 0.5
+        recv = torch.full((1000,), -1.0, dtype=torch.float64, device='cuda')
+        _lib.check(ctx.lib.sbm_allgather_norms(ctx.handle, comm, _lib.dev_ptr(send), 1000, _lib.dev_ptr(recv)),
+                   'sbm_allgather_norms')
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(recv, send)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
