@@ -229,6 +229,13 @@ int sbm_jacobian_batch(sbm_project* p, const double* Theta_dev, int32_t V,
                        double* norms_dev, double* grad_dev, int32_t* status_dev,
                        int32_t* n_steps_dev);
 
+/* Richardson extrapolation for SBM_IMPLICIT_MIDPOINT evaluations of this project: levels = 1 integrates
+ * every trajectory twice (step_mult and 2*step_mult) and combines the sampled states and sensitivities as
+ * (4 fine - coarse)/3 BEFORE the residual / Jacobian assembly; levels = 2 adds a third run (h^4 term);
+ * 0 (default) switches it off.  Other methods ignore it.  Host-level counterpart of
+ * OdeModel's ``extrapolate`` option. */
+int sbm_project_set_extrapolation(sbm_project* p, int32_t levels);
+
 /* bytes of device scratch the project keeps for V vectors (allocated lazily,
  * grown on demand, freed at unload) */
 int64_t sbm_project_scratch_bytes(const sbm_project* p, int32_t V, int32_t with_sens);

@@ -74,6 +74,7 @@ SIGNATURES = {
     'sbm_project_unload': (ctypes.c_int, [_vp]),
     'sbm_residuals_batch': (ctypes.c_int, [_vp, _vp, _i32, _opts_p, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sbm_jacobian_batch': (ctypes.c_int, [_vp, _vp, _i32, _opts_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'sbm_project_set_extrapolation': (ctypes.c_int, [_vp, _i32]),
     'sbm_project_scratch_bytes': (ctypes.c_int64, [_vp, _i32, _i32]),
     'sbm_allgather_norms': (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     'sbm_lm_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),

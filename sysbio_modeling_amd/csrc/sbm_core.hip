@@ -97,6 +97,10 @@ struct sbm_project {
   DevBuf<double> P, Y, S, sims, sf;
   DevBuf<int32_t> traj_status, traj_steps, traj_rej, goff, glen;
   int scratch_V = 0;
+  // Richardson extrapolation of the implicit-midpoint runs (sbm_project_set_extrapolation)
+  int richardson = 0;
+  DevBuf<double> Yx[2], Sx[2];
+  DevBuf<int32_t> statx, stepsx;
 };
 
 extern "C" const char* sbm_last_error(void) { return g_err; }
@@ -824,6 +828,8 @@ extern "C" int sbm_project_unload(sbm_project* p) {
   p->sfp_group.release(); p->sfp_mean.release(); p->sfp_sigma.release();
   p->P.release(); p->Y.release(); p->S.release(); p->sims.release(); p->sf.release();
   p->traj_status.release(); p->traj_steps.release(); p->traj_rej.release(); p->goff.release(); p->glen.release();
+  for (int l = 0; l < 2; ++l) { p->Yx[l].release(); p->Sx[l].release(); }
+  p->statx.release(); p->stepsx.release();
   delete p;
   return 0;
 }
@@ -834,6 +840,32 @@ extern "C" int64_t sbm_project_scratch_bytes(const sbm_project* p, int32_t V, in
   int64_t b = T * p->n_params * 8 + T * p->n_t_max * p->n_vars * 8 + T * 5 * 4 + (int64_t)V * (p->R + p->G) * 8;
   if (with_sens) b += T * p->n_t_max * p->n_vars * (int64_t)p->n_sens * 8;
   return b;
+}
+
+// Richardson combination of runs with step sizes h, h/2 (, h/4) of a symmetric one-step method (error
+// expansion in h^2):  levels = 1: (4 b - a) / 3;  levels = 2: (16 (4 c - b)/3 - (4 b - a)/3) / 15.  In place in a.
+__global__ void k_richardson(double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ c,
+                             size_t n, int levels) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double t1 = (4.0 * b[i] - a[i]) * (1.0 / 3.0);
+  if (levels == 1) { a[i] = t1; return; }
+  const double t2 = (4.0 * c[i] - b[i]) * (1.0 / 3.0);
+  a[i] = (16.0 * t2 - t1) * (1.0 / 15.0);
+}
+__global__ void k_merge_status(int32_t* __restrict__ st, int32_t* __restrict__ steps, const int32_t* __restrict__ st2,
+                               const int32_t* __restrict__ steps2, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st[i] = max(st[i], st2[i]);
+  steps[i] += steps2[i];
+}
+
+extern "C" int sbm_project_set_extrapolation(sbm_project* p, int32_t levels) {
+  if (!p) return sbm_fail(SBM_E_ARG, "sbm_project_set_extrapolation: project is NULL");
+  if (levels < 0 || levels > 2) return sbm_fail(SBM_E_ARG, "sbm_project_set_extrapolation: levels %d (0, 1 or 2)", levels);
+  p->richardson = levels;
+  return 0;
 }
 
 static int launch_assemble(const AssembleArgs& g, int V, hipStream_t s, const char* who) {
@@ -887,6 +919,33 @@ static int project_run(sbm_project* p, const double* Theta, int V, const sbm_int
   a.n_traj = (int32_t)T; a.n_t = nt; a.opts = *opts;
   rc = sens ? launch_sens(m, a, who) : launch(m, SBM_KIND_STATE, a, who);
   if (rc) return rc;
+  const int levels = (opts->method == SBM_IMPLICIT_MIDPOINT) ? p->richardson : 0;
+  if (levels > 0) {
+    // the same ensemble again with every step halved (and halved again), then the combination in place
+    const size_t nY = T * nt * NV, nS = T * nt * NV * NK;
+    const bool grow2 = nY > p->Yx[0].n || (levels > 1 && nY > p->Yx[1].n) || (sens && (nS > p->Sx[0].n || (levels > 1 && nS > p->Sx[1].n))) ||
+                       T > p->statx.n;
+    if (grow2) SBM_HIP(hipStreamSynchronize(s));
+    if (p->statx.reserve(T) || p->stepsx.reserve(T)) return sbm_fail(SBM_E_HIP, "%s: out of device memory", who);
+    const int mult0 = opts->step_mult > 0 ? opts->step_mult : 1;
+    for (int l = 0; l < levels; ++l) {
+      if (p->Yx[l].reserve(nY) || (sens && p->Sx[l].reserve(nS))) return sbm_fail(SBM_E_HIP, "%s: out of device memory", who);
+      sbm_kernel_args b = a;
+      b.Y = p->Yx[l].p; b.S = sens ? p->Sx[l].p : nullptr;
+      b.status = p->statx.p; b.n_steps = p->stepsx.p; b.n_reject = nullptr;
+      b.opts.step_mult = mult0 << (l + 1);
+      rc = sens ? launch_sens(m, b, who) : launch(m, SBM_KIND_STATE, b, who);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_merge_status, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, p->traj_status.p,
+                         p->traj_steps.p, p->statx.p, p->stepsx.p, (int)T);
+    }
+    hipLaunchKernelGGL(k_richardson, dim3((unsigned)((nY + 255) / 256)), dim3(256), 0, s, p->Y.p, p->Yx[0].p,
+                       levels > 1 ? p->Yx[1].p : nullptr, nY, levels);
+    if (sens)
+      hipLaunchKernelGGL(k_richardson, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, s, p->S.p, p->Sx[0].p,
+                         levels > 1 ? p->Sx[1].p : nullptr, nS, levels);
+    SBM_HIP(hipGetLastError());
+  }
 
   AssembleArgs g;
   memset(&g, 0, sizeof(g));

@@ -346,6 +346,7 @@ class Project(object):
         _lib.check(lib.sbm_project_load(self._model.device_model.handle, ctypes.byref(desc), ctypes.byref(h)),
                    'sbm_project_load')
         self._device_project = h
+        self._richardson_levels = 0      # a freshly loaded project starts without extrapolation
         return h
 
     # ------------------------------------------------------------------
@@ -532,9 +533,16 @@ class Project(object):
     def _opts(self, **overrides):
         o = dict(self.integrator_options)
         o.update(overrides)
-        if str(o.get('method', 'dopri45')).lower() in ('rk4', 'rk4_fixed') and not o.get('h0', 0) > 0:
+        levels = int(o.pop('extrapolate', 0) or 0)
+        fixed = ('rk4', 'rk4_fixed') + _lib.FIXED_STEP_IMPLICIT
+        if str(o.get('method', 'dopri45')).lower() in fixed and not o.get('h0', 0) > 0:
             o['t_end'] = max(g[-1] for g in self._rows['grids'])
             o.setdefault('n_steps', 4096)
+        # Richardson levels of the implicit integrator are a property of the loaded project
+        if levels != getattr(self, '_richardson_levels', 0):
+            _lib.check(_lib.load_library().sbm_project_set_extrapolation(self._device(), levels),
+                       'sbm_project_set_extrapolation')
+            self._richardson_levels = levels
         return _lib.make_opts(**o)
 
     def _theta_dev(self, thetas):
