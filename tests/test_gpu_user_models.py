@@ -94,3 +94,60 @@ def test_more_sensitivity_columns_than_lanes():
     assert np.allclose(S_rk, S, rtol=1e-7, atol=1e-9)
     with pytest.raises(Exception):
         m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=64)   # needs n_sens <= 64
+
+
+def _random_network(seed, n):
+    """Random rate-law network: every species is produced from one or two others (mass action or
+    saturating), degraded linearly, some with product inhibition; bounded by construction."""
+    import sympy
+    from collections import OrderedDict
+    from sysbio_modeling_amd.symbolic.emit import ModelSpec
+    rng = np.random.default_rng(seed)
+    xs = [sympy.Symbol('x%d' % i) for i in range(n)]
+    params, eq = [], OrderedDict()
+
+    def par(name):
+        params.append(name)
+        return sympy.Symbol(name)
+    for i in range(n):
+        kind = int(rng.integers(0, 4))
+        d = par('d%d' % i)
+        if i == 0 or kind == 0:
+            rhs = par('k%d' % i) - d * xs[i]
+        elif kind == 1:
+            j = int(rng.integers(0, n))
+            rhs = par('k%d' % i) * xs[j] / (1 + xs[j]) - d * xs[i]
+        elif kind == 2:
+            j, l = int(rng.integers(0, n)), int(rng.integers(0, n))
+            rhs = par('k%d' % i) * xs[j] / ((1 + xs[j]) * (1 + xs[l] / par('K%d' % i))) - d * xs[i]
+        else:
+            j = int(rng.integers(0, i))
+            rhs = par('k%d' % i) * xs[j] - d * xs[i] * xs[i]
+        eq['x%d' % i] = rhs
+    return ModelSpec(name='rand%d_%d' % (n, seed), variables=[str(x) for x in xs], params=params, equations=eq)
+
+
+@pytest.mark.parametrize('seed,n', [(1, 6), (2, 11), (3, 17)])
+def test_random_networks_all_variants(seed, n):
+    """Emitter + kernels on networks nobody tuned them for: whatever classes, row splits and halo terms
+    the generator comes up with, every variant must reproduce SciPy odeint on the generated callables."""
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    from sysbio_modeling_amd.model import OdeModel
+    gm = GeneratedModel(_random_network(seed, n))
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=gm.spec.name)
+    rng = np.random.default_rng(100 + seed)
+    P = np.exp(rng.uniform(np.log(0.2), np.log(2.0), (4, len(gm.param_order))))
+    t = np.linspace(0, 20.0, 1000)
+    idx = np.array([0, 333, 999])
+    ref = [_odeint_ref(gm, P[v], t) for v in (0, 3)]
+    for variant in ('per_wave', 'row_lane', 'row_group'):
+        for method, kw in (('dopri45', {}), ('rk4', {'n_steps': 8192})):
+            S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant, method=method, **kw)
+            assert m.last_info['status'].tolist() == [0, 0, 0, 0]
+            for k, v in enumerate((0, 3)):
+                assert parity_err(Y[v], ref[k][0][idx]) <= 1.0, (variant, method)
+                assert parity_err(S[v], ref[k][1][idx]) <= 1.0, (variant, method)
+    Y = m.simulate_batch(P, t[idx])
+    assert parity_err(Y[0], ref[0][0][idx]) <= 1.0
+    S = m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=4096, extrapolate=1, rtol=1e-11, atol=1e-13)
+    assert parity_err(S[3], ref[1][1][idx]) <= 1.0
