@@ -67,10 +67,10 @@ typedef struct sbm_integrator_opts {
  * side by side), and handed to the columns through LDS.  ROW_GROUP: ROW_LANE with
  * the rows of a column split over several lanes, so that all 64 lanes carry
  * equations and the Runge-Kutta stages fit the register file.  ROW_LANE / ROW_GROUP
- * need n_vars <= 64 and n_sens <= 64; AUTO picks ROW_GROUP when the model's rows
- * fall into few classes and the model generator found a paying split, else ROW_LANE
- * under the first condition, else PER_WAVE.  A forced variant the model does not
- * support falls back in the same order. */
+ * need n_vars <= 64 and n_sens <= 64; AUTO picks ROW_GROUP when the model generator
+ * found a paying split, else ROW_LANE when the model fits, else PER_WAVE.  A forced
+ * variant the model does not support falls back in the same order.  For the state-only
+ * entry points PER_WAVE selects the one-trajectory-per-lane kernel. */
 enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2, SBM_VARIANT_ROW_GROUP = 3 };
 
 /* per-trajectory status written next to the results (the reference does not

@@ -1376,10 +1376,12 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     }
   }
   if (kind == SBM_KIND_SENS) {
-    // row-lane kernel whenever the model fits one row + one column per lane and its rows fall into
-    // few enough classes to pay (otherwise every class runs alone on a handful of lanes)
+    // row-lane / row-group kernels whenever the model fits one row + one column per lane.  Even when
+    // every row is a class of its own they evaluate NCLASS <= NV row bodies per stage where the per-wave
+    // kernel evaluates all NV rows on every lane (measured on random networks with 6 and 9 classes of 11
+    // and 17 rows: 1.6x faster than per-wave)
     constexpr bool kRowLaneOk = (M::NV <= 64 && M::NK <= 64);
-    constexpr bool kRowLanePays = kRowLaneOk && (M::RL_NCLASS * 4 <= M::NV + 3);
+    constexpr bool kRowLanePays = kRowLaneOk;
     const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
                          (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays);
     // row-group kernel: the row-lane kernel with the rows of a column split over several lanes,
@@ -1409,7 +1411,7 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     else hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
   } else {
     // one trajectory per wave until the chip is full of lane-per-trajectory waves anyway
-    constexpr bool kRowsOk = (M::NV <= 64) && (M::RL_NCLASS * 4 <= M::NV + 3);
+    constexpr bool kRowsOk = (M::NV <= 64);
     if constexpr (kRowsOk) {
       if (a.n_traj < 65536 && a.opts.variant != SBM_VARIANT_PER_WAVE) {
         dim3 grid(a.n_traj), block(64);
