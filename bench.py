@@ -88,6 +88,31 @@ def cpu_baseline(gm, theta_rows, budget_s=12.0, max_vectors=4096):
             "ms_per_vector": 1e3 * dt / max(n, 1)}
 
 
+def residual_parity(gm, proj, theta_rows, res_gpu, jac_gpu, n_check=3):
+    """BASELINE.json's second figure: residual (and Jacobian) error of the timed GPU pass against the
+    SciPy restatement of the reference's Project on the same inputs, for the first few vectors.  Reported
+    in the units of the parity tolerance |gpu - ref| <= 1e-8 |ref| + 5e-9 of the underlying trajectories;
+    residual rows are trajectories divided by sigma ~ 0.06, so their floor scales by 1 / sigma;
+    ``residual_rel_err`` is |r_gpu - r_scipy|_2 / |r_scipy|_2, the worst of the checked vectors."""
+    from oracle.project_oracle import ProjectOracle
+    po = ProjectOracle(gm, list(proj.experiments), proj._model_parameter_settings,
+                       {k: v for k, v in proj._measurement_to_model_map_raw.items()},
+                       sf_groups=[g if len(g) > 1 else g[0] for g in proj._loss_function.groups])
+    sig = proj.descriptor_arrays()['row_sigma']
+    worst_r = worst_rel = worst_j = 0.0
+    for v in range(n_check):
+        rr = po.residuals(theta_rows[v])
+        Jr = po.calc_project_jacobian(theta_rows[v])
+        d = np.abs(res_gpu[v] - rr)
+        worst_r = max(worst_r, float(np.max(d / (1e-8 * np.abs(rr) + 5e-9 / sig))))
+        worst_rel = max(worst_rel, float(np.linalg.norm(res_gpu[v] - rr) / np.linalg.norm(rr)))
+        worst_j = max(worst_j, float(np.max(np.abs(jac_gpu[v] - Jr) / (1e-8 * np.abs(Jr) + 1e-8 * np.abs(Jr).max()))))
+    return {"vectors_checked": n_check, "residual_err_in_tolerance_units": worst_r,
+            "residual_rel_err": worst_rel, "jacobian_err_in_tolerance_units": worst_j,
+            "tolerance": "|gpu - scipy| <= 1e-8 |scipy| + 5e-9 / sigma (residuals); 1e-8 (|J| + max|J|) (Jacobian)",
+            "reference": "ProjectOracle: scipy.integrate.odeint rtol=atol=1e-10, reference_compat Jacobian"}
+
+
 def _cpu_worker(rows_budget):
     """one process of the all-cores baseline: integrates its share of the sample for `budget` seconds"""
     rows, budget = rows_budget
@@ -112,7 +137,7 @@ def cpu_baseline_all_cores(theta_rows, budget_s=10.0):
     are spawned, not forked)."""
     import multiprocessing as mp
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
+    cores = max(1, min(cores, 16))     # a one-GPU box's CPU share
     per = max(1, len(theta_rows) // cores)
     # every worker starts at its own offset of the ensemble and stops on its time budget
     chunks = [(np.roll(theta_rows, -i * per, axis=0), budget_s) for i in range(cores)]
@@ -350,6 +375,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(gm, theta)
         result["cpu_baseline_all_cores"] = cpu_all
+        result["cpu_baseline"]["parity_of_timed_pass"] = residual_parity(
+            gm, proj, theta, out['res'][:3].cpu().numpy(), out['J'][:3].cpu().numpy())
     elif rank == 0:
         result["cpu_baseline"] = None
     if extras:

@@ -71,6 +71,7 @@ class Project(object):
         self._scale_factor_priors = []
 
         self._measurement_to_model_map = {}
+        self._measurement_to_model_map_raw = dict(measurement_to_model_map)   # as given (introspection)
         self._make_mapping(measurement_to_model_map)
 
         self._device_project = None
