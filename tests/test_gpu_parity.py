@@ -714,3 +714,30 @@ def test_c_abi_allgather_norms_single_rank():
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_large_batch_indexing(gpu_models):
+    """16 384 vectors x 17 rows x 820 values = 1.8 GB of sensitivities in one call (past 2^31 bytes and
+    2^28 elements): every trajectory must equal what a small batch gives for the same parameters."""
+    import torch
+    from sysbio_modeling_amd import models_zoo, _lib
+    m = gpu_models('cascade20')
+    V = 16384
+    _, P = models_zoo.cascade_ensemble(V)
+    grid = np.linspace(0, 100, 1000)
+    t = np.concatenate([[0.0], grid[np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)]])
+    dm = m.device_model
+    Pd, td = torch.from_numpy(P).cuda(), torch.from_numpy(t).cuda()
+    Y = torch.empty((V, 17, 20), dtype=torch.float64, device='cuda')
+    S = torch.full((V, 17, 20, 40), float('nan'), dtype=torch.float64, device='cuda')
+    st = torch.empty(V, dtype=torch.int32, device='cuda')
+    ns = torch.empty(V, dtype=torch.int32, device='cuda')
+    dm.sens_dev(Pd, td, None, _lib.make_opts(t0=0.0), Y, S, st, ns, None)
+    torch.cuda.synchronize()
+    assert int((st != 0).sum()) == 0 and bool(torch.isfinite(S).all())
+    pick = [0, 1, 4095, 4096, 8191, 12345, V - 1]
+    S_small, Y_small = m.calc_jacobian_batch(P[pick], t, return_states=True)
+    assert np.array_equal(S[pick].cpu().numpy().reshape(len(pick), 17, 800), S_small)
+    assert np.array_equal(Y[pick].cpu().numpy(), Y_small)
+    del S, Y
+    torch.cuda.empty_cache()
