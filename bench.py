@@ -278,7 +278,7 @@ def main():
                         "binding resource is VALU issue (profiles/r01c/pmc_summary.json)"}
 
     extras = {}
-    if not args.no_extras and rank == 0:
+    if not args.no_extras and rank == 0 and world == 1:   # single-GPU micro-benchmarks
         def time_kernel(kind, o, reps=3):
             for _ in range(1):
                 (dm.sens_dev(theta_p, tg, None, o, Yk, Sk, None, ns_k, None) if kind == 'sens'
