@@ -7,7 +7,8 @@ on the CPU in dense numpy, step for step as csrc/sbm_integrators.hpp::sbm_imid_k
 the kernel can be checked at the level of the algorithm (tests/test_gpu_implicit.py), while parity
 with the reference's results is checked against ``odeint_oracle`` (LSODA) after extrapolation.
 
-  y_{n+1} = y_n + h f(ybar), ybar = (y_n + y_{n+1})/2;  Newton from ybar = y_n:
+  y_{n+1} = y_n + h f(ybar), ybar = (y_n + y_{n+1})/2;  Newton from ybar = y_n + (previous increment)/2
+  (rescaled when the step size changes between output intervals; y_n for the first step):
       (I - h/2 J_y(ybar)) delta = ybar - y_n - h/2 f(ybar),  ybar -= delta,
       until max |delta_i| / (atol + rtol |ybar_i|) <= 1 (at most 12 iterations)
   S_{n+1} = 2 Sbar - S_n,  (I - h/2 J_y) Sbar = S_n + h/2 J_p, with J_y, J_p of the last evaluated iterate
@@ -60,6 +61,7 @@ def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None
     t = float(t0)
     n_steps = n_newton = 0
     eye = np.eye(n)
+    dy_prev, hs_prev = np.zeros(n), 0.0
     for io, target in enumerate(t_out):
         dt = target - t
         if dt > 0:
@@ -68,9 +70,11 @@ def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None
             hs = dt / ns
             hh = 0.5 * hs
             t_start = t
+            dy_prev = dy_prev * (hs / hs_prev if hs_prev > 0 else 0.0)
+            hs_prev = hs
             for s in range(ns):
                 tm = t_start + (s + 0.5) * hs
-                yb = y.copy()
+                yb = y + 0.5 * dy_prev
                 conv = False
                 for _ in range(MAXIT):
                     n_newton += 1
@@ -83,6 +87,7 @@ def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None
                         break
                 if not conv:
                     raise RuntimeError("Newton did not converge")
+                dy_prev = 2.0 * (yb - y)
                 y = 2.0 * yb - y
                 if with_sens:
                     Sb = np.linalg.solve(M, S + hh * Jp)

@@ -1256,6 +1256,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   double m[M::IM_NM];
 #pragma unroll
   for (int e = 0; e < M::IM_NM; ++e) m[e] = 0.0;
+  double dy_prev = 0.0, hs_prev = 0.0;   // increment of the previous step (this lane's component), its step size
 
   for (int io = 0; io < glen; ++io) {
     const double target = tg[io];
@@ -1267,9 +1268,13 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
       if (!failed) {
         const double hs = dt / ns, hh = 0.5 * hs;
         const double t0 = t;
+        // Newton starts from the midpoint the previous step's increment predicts (free, and good for the
+        // smooth solutions a fixed step resolves): 2.6 -> about 2 iterations per step on stiff50
+        dy_prev *= (hs_prev > 0.0) ? hs / hs_prev : 0.0;
+        hs_prev = hs;
         for (int s = 0; s < ns && !failed; ++s) {
           const double tm = fma((double)s + 0.5, hs, t0);
-          double yb = y;
+          double yb = fma(0.5, dy_prev, y);
           bool conv = false;
           for (int it = 0; it < MAXIT && !conv; ++it) {
             ++n_newton;
@@ -1323,6 +1328,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
           }
           if (!failed && !conv) { status = SBM_NEWTON_FAIL; failed = true; }
           if (failed) break;
+          dy_prev = 2.0 * (yb - y);
           y = fma(2.0, yb, -y);
           if (with_sens) {
             // J_y (the factors in m) and J_p (A) are those of the last evaluated iterate: within the
