@@ -631,7 +631,6 @@ __global__ void __launch_bounds__(64) sbm_state_kernel(sbm_kernel_args a) {
 template <class M>
 struct SbmRowLaneShared {
   double Y[64];                 // stage state, one component per row lane
-  double JY[M::NJY + 2];        // J_y non-zeros (+ a spare slot for unused outputs)
   double A[M::NV * 64 + 2];     // A[i][c] = J_p[i][c]; zero where J_p is structurally zero
 };
 
@@ -647,18 +646,13 @@ struct RowLaneSystem {
   int cls;                       // class of this lane's row, -1 on lanes without a row
   int yidx[M::RL_MAXYS];         // which state feeds operand slot s
   double ps[M::RL_MAXPS];        // this row's parameters
-  int jyout[M::RL_MAXJY];        // where this row's J_y entries go (LDS-list variant)
   int apos[M::RL_MAXJP];         // where this row's J_p entries go in A
   double sj[M::RL_NSTATIC > 0 ? M::RL_NSTATIC : 1];  // parameter-only J_y entries, wave-uniform
 
   // LDS traffic of ONE wave is processed in issue order, so a ds_read issued after a ds_write of
   // another lane sees that write: no barrier and no waitcnt is needed between the phases below,
   // only a compiler-level fence that keeps the memory operations in program order.
-#ifdef SBM_RL_BARRIER
-  __device__ __forceinline__ static void lds_order() { __syncthreads(); }
-#else
   __device__ __forceinline__ static void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
-#endif
 
   struct Token {
     double f;                  // derivative of this lane's state component
@@ -689,10 +683,6 @@ struct RowLaneSystem {
     lds_order();
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
-#ifdef SBM_RL_JY_LDS
-#pragma unroll
-    for (int s = 0; s < M::RL_MAXJY; ++s) sh->JY[jyout[s]] = k.jy[s];
-#endif
     lds_order();
     return k;
   }
@@ -708,12 +698,7 @@ struct RowLaneSystem {
 #pragma unroll
     for (int i = 0; i < NV; ++i) acol[i] = sh->A[i * 64 + lane];
     lds_order();
-#ifdef SBM_RL_JY_LDS
-    M::apply_rowlane_lds(sh->JY, acol, zc, dc);
-    lds_order();
-#else
     M::apply_rowlane(k.jy, sj, acol, zc, dc);
-#endif
 #pragma unroll
     for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
   }
@@ -749,7 +734,6 @@ __global__ void __launch_bounds__(64) sbm_sens_rowlane_kernel(sbm_kernel_args a)
   const int lane = threadIdx.x;
 
   for (int i = lane; i < NV * 64 + 2; i += 64) sh.A[i] = 0.0;
-  for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
   sh.Y[lane] = 0.0;
 
   Sys sys;
@@ -763,8 +747,6 @@ __global__ void __launch_bounds__(64) sbm_sens_rowlane_kernel(sbm_kernel_args a)
   for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[s] = M::rl_ys(s, row);
 #pragma unroll
   for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[s] = P[M::rl_ps(s, row)];
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXJY; ++s) sys.jyout[s] = has_row ? M::rl_jyout(s, row) : M::NJY + 1;
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJP; ++s) sys.apos[s] = has_row ? M::rl_apos(s, row) : NV * 64 + 1;
   __syncthreads();

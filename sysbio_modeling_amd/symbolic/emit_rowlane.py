@@ -191,16 +191,5 @@ def emit_rowlane_members(spec, d, meta, make_printer):
                 r, k = where[e_idx]
                 expr = "fma(SBM_LANE_BCAST(jy[%d], %d), z[%d], %s)" % (k, r, c, expr)
         L.append("    dz[%d] = %s;" % (i, expr))
-    L += ["  }",
-          "  // same with the J_y non-zeros read from an LDS list (jysh[e], wave-uniform addresses)",
-          "  template <int NZ>",
-          "  __device__ __forceinline__ static void apply_rowlane_lds(const double* jysh, const double (&acol)[NV],",
-          "                                                           const double (&z)[NZ], double (&dz)[NZ]) {",
-          "    (void)jysh;"]
-    for i in range(n):
-        expr = "acol[%d]" % i
-        for e_idx, c in d.jy_rows[i]:
-            expr = "fma(jysh[%d], z[%d], %s)" % (e_idx, c, expr)
-        L.append("    dz[%d] = %s;" % (i, expr))
     L += ["  }"]
     return L
