@@ -43,10 +43,15 @@ enum {
                              * model's sparse LU; sensitivities = exact derivative of the scheme.
                              * Second order with an h^2 error expansion (extrapolate two runs).
                              * Needs n_vars <= 64 and n_sens <= 64. */
+  ,
+  SBM_IMPLICIT_MIDPOINT_GRADED = 3 /* the same with a graded first step: it is cut into 13 midpoint substeps
+                             * of sizes h0 * 2^-12, 2^-12, 2^-11, ..., 1/2.  For initial conditions off a
+                             * fast manifold -- the reference always starts from y = 0
+                             * (model/ode_model.py:151-152) -- whose initial layer no fixed step resolves. */
 };
 
 typedef struct sbm_integrator_opts {
-  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_IMPLICIT_MIDPOINT      */
+  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_IMPLICIT_MIDPOINT[_GRADED] */
   int32_t max_steps; /* per trajectory, accepted + rejected; <=0 -> 1000000      */
   double rtol;       /* DOPRI45 relative tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
   double atol;       /* DOPRI45 absolute tolerance; IMPLICIT_MIDPOINT: Newton tolerance */

@@ -13,6 +13,8 @@ with the reference's results is checked against ``odeint_oracle`` (LSODA) after 
       until max |delta_i| / (atol + rtol |ybar_i|) <= 1 (at most 12 iterations)
   S_{n+1} = 2 Sbar - S_n,  (I - h/2 J_y) Sbar = S_n + h/2 J_p, with J_y, J_p of the last evaluated iterate
   each output interval is cut into step_mult * ceil(dt / h0) equal steps.
+  graded=True (SBM_IMPLICIT_MIDPOINT_GRADED): the first step of the trajectory is cut into 13 midpoint
+  substeps of sizes hs * 2^-12, 2^-12, 2^-11, ..., 1/2 to resolve an initial layer.
 
 J_y and J_p are read off the generated sensitivity RHS (S' = J_y S + J_p): no second code path.
 Parity: "scheme-level" only -- pinned to LSODA through the convergence tests, not to reference vectors.
@@ -24,6 +26,7 @@ from __future__ import annotations
 import numpy as np
 
 MAXIT = 12
+GRADE = 12
 
 
 def jacobians(gm, y, t, p):
@@ -50,7 +53,8 @@ def jacobians(gm, y, t, p):
     return f, Jy, Jp
 
 
-def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None, with_sens=True, step_mult=1):
+def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None, with_sens=True, step_mult=1,
+              graded=False):
     """Returns (Y (len(t_out), n), S (len(t_out), n*k) or None, n_steps, n_newton)."""
     n, k = gm.n_vars, gm.n_sens
     p = np.asarray(p, dtype=float)
@@ -73,7 +77,16 @@ def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None
             dy_prev = dy_prev * (hs / hs_prev if hs_prev > 0 else 0.0)
             hs_prev = hs
             for s in range(ns):
-                tm = t_start + (s + 0.5) * hs
+              # graded first step: substeps hs * 2^-12, 2^-12, 2^-11, ..., 1/2 (a fixed pattern relative to hs)
+              if graded and n_steps == 0:
+                  subs = [hs * 2.0 ** -GRADE] + [hs * 2.0 ** -(GRADE - j + 1) for j in range(1, GRADE + 1)]
+              else:
+                  subs = [hs]
+              t_sub = t_start + s * hs
+              for sub, hsub in enumerate(subs):
+                hh = 0.5 * hsub
+                tm = t_sub + hh
+                t_sub += hsub
                 yb = y + 0.5 * dy_prev
                 conv = False
                 for _ in range(MAXIT):
@@ -87,12 +100,12 @@ def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None
                         break
                 if not conv:
                     raise RuntimeError("Newton did not converge")
-                dy_prev = 2.0 * (yb - y)
+                dy_prev = 2.0 * (yb - y) * (2.0 if (len(subs) > 1 and sub > 0) else 1.0)
                 y = 2.0 * yb - y
                 if with_sens:
                     Sb = np.linalg.solve(M, S + hh * Jp)
                     S = 2.0 * Sb - S
-                n_steps += 1
+              n_steps += 1
             t = target
         Y_out[io] = y
         S_out[io] = S.ravel()

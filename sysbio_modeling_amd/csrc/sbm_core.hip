@@ -201,7 +201,7 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: RK4 needs h0 > 0", who);
   } else if (o->method == SBM_DOPRI45) {
     if (!(o->rtol > 0.0) || !(o->atol > 0.0)) return sbm_fail(SBM_E_ARG, "%s: DOPRI45 needs rtol, atol > 0", who);
-  } else if (o->method == SBM_IMPLICIT_MIDPOINT) {
+  } else if (o->method == SBM_IMPLICIT_MIDPOINT || o->method == SBM_IMPLICIT_MIDPOINT_GRADED) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: implicit midpoint needs h0 > 0", who);
   } else {
     return sbm_fail(SBM_E_ARG, "%s: unknown method %d", who, o->method);
@@ -919,7 +919,7 @@ static int project_run(sbm_project* p, const double* Theta, int V, const sbm_int
   a.n_traj = (int32_t)T; a.n_t = nt; a.opts = *opts;
   rc = sens ? launch_sens(m, a, who) : launch(m, SBM_KIND_STATE, a, who);
   if (rc) return rc;
-  const int levels = (opts->method == SBM_IMPLICIT_MIDPOINT) ? p->richardson : 0;
+  const int levels = (opts->method == SBM_IMPLICIT_MIDPOINT || opts->method == SBM_IMPLICIT_MIDPOINT_GRADED) ? p->richardson : 0;
   if (levels > 0) {
     // the same ensemble again with every step halved (and halved again), then the combination in place
     const size_t nY = T * nt * NV, nS = T * nt * NV * NK;

@@ -148,3 +148,57 @@ def test_project_on_the_stiff_model_with_extrapolation(gpu_models, golden):
     # without extrapolation the same call is only second-order accurate
     out0 = proj.evaluate_batch(theta, method='implicit_midpoint', n_steps=4096, rtol=1e-10, atol=1e-12)
     assert parity_err(out0['sims'][0], np.concatenate([Yr[0][:, species[k]] for k in order])) > 50.0
+
+
+STIFF_MOTIF = """
+#*! Parameters Start
+    k_on = p[0]
+    k_off = p[1]
+    k_cat = p[2]
+    k_deg = p[3]
+#*! Parameters End
+#*! Variables Start
+    _c = y[0]
+    _p = y[1]
+#*! Variables End
+#*! Differential Equations Start
+    d__c = k_on * (1.5 - _c) * (1.0 / (1.0 + _p)) - k_off * _c - k_cat * _c
+    d__p = k_cat * _c - k_deg * _p
+#*! Differential Equations End
+"""
+
+
+def test_graded_first_step_for_inconsistent_initial_conditions():
+    """The reference always starts from y = 0 (ode_model.py:151-152); with binding rates of 2e3 that is far
+    off the fast manifold, and the initial layer (width ~3e-4) is thinner than any affordable fixed step.
+    SBM_IMPLICIT_MIDPOINT_GRADED cuts the first step into 13 geometrically growing substeps: scheme-level
+    agreement with the oracle, and an order of magnitude closer to the reference's LSODA result than the
+    plain rule at the same cost (13 extra steps).  Neither reaches the 1e-8 of a consistent start: the
+    midpoint rule is not L-stable and loses order on the remains of the layer."""
+    from oracle import imid_oracle, odeint_oracle as oo
+    from sysbio_modeling_amd.symbolic import make_ode_model
+    from sysbio_modeling_amd.model import OdeModel
+    gm = make_ode_model(STIFF_MOTIF, name='stiff_motif2')
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='stiff_motif2')
+    P = np.array([[2e3, 5e2, 1e3, 0.1], [1e3, 8e2, 2e3, 0.15]])
+    grid = np.linspace(0, 30.0, 1000)
+    idx = np.array([100, 500, 999])
+    t_out = _from_zero(grid[idx])
+    Yr = np.stack([oo.simulate(gm, p, grid)[idx] for p in P])
+    Sr = np.stack([oo.calc_jacobian(gm, p, grid)[idx] for p in P])
+    # scheme level
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_midpoint_graded', h0=0.05,
+                                 rtol=1e-11, atol=1e-13)
+    Yo, So, ns, _ = imid_oracle.integrate(gm, P[0], t_out[1:], 0.05, rtol=1e-11, atol=1e-13, graded=True)
+    assert m.last_info['n_steps'][0] == ns
+    assert np.allclose(Y[0, 1:], Yo, rtol=1e-9, atol=1e-12) and np.allclose(S[0, 1:], So, rtol=1e-8, atol=1e-10 * np.abs(So).max())
+    # reference level
+    def rel(A, B):
+        return np.max(np.abs(A - B) / (np.abs(B) + 1e-6 * np.abs(B).max()))
+    kw = dict(n_steps=4096, extrapolate=1, rtol=1e-11, atol=1e-13)
+    S_g, Y_g = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_midpoint_graded', **kw)
+    S_p, Y_p = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_midpoint', **kw)
+    e_g = max(rel(Y_g[:, 1:], Yr), rel(S_g[:, 1:], Sr))
+    e_p = max(rel(Y_p[:, 1:], Yr), rel(S_p[:, 1:], Sr))
+    assert e_g < 3e-6, e_g
+    assert e_p > 3.0 * e_g, (e_p, e_g)
