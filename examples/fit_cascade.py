@@ -31,16 +31,16 @@ def main():
     starts = theta_true[None, :] + 0.3 * rng.standard_normal((n_starts, theta_true.size))
     c0 = proj.calc_sum_square_residuals_batch(starts)
     t0 = time.time()
-    fit = proj.fit_batch(starts, max_iter=40)
+    fit = proj.fit_batch(starts, max_iter=150)
     dt = time.time() - t0
     best = int(np.argmin(fit['cost']))
-    print("LM: %d starts x 40 iterations in %.2f s (%d trajectory integrations with sensitivities)"
+    print("LM: %d starts x up to 150 iterations in %.2f s (%d trajectory integrations with sensitivities)"
           % (n_starts, dt, fit['n_evaluations'] * 8))
     print("    cost: start median %.1f -> fit median %.3f, best %.3f (truth: %.3f)"
           % (np.median(c0), np.median(fit['cost']), fit['cost'][best], proj.calc_sum_square_residuals(theta_true)))
     t0 = time.time()
     ens, ens_F, ratio = ensemble_log_params_batch(proj, np.tile(fit['theta'][best], (64, 1)), steps=200, seeds=1,
-                                                  sing_val_cutoff=1e-4, energy='rss')
+                                                  sing_val_cutoff=1e-4, step_scale=0.3, energy='rss')
     print("MCMC: 64 chains x 200 steps in %.2f s, acceptance %.2f" % (time.time() - t0, ratio.mean()))
     sd = ens[50:].reshape(-1, ens.shape[-1]).std(axis=0)
     names = [n for n, _ in proj.get_ordered_project_params()]
