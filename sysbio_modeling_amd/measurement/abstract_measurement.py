@@ -1,21 +1,26 @@
-"""Measurement base type (reference measurement/abstract_measurement.py:8-24)."""
-from abc import ABCMeta, abstractmethod
+"""Base of the measurement containers.
 
+Same validation as the reference (measurement/abstract_measurement.py:8-24): without error bars every
+point weighs the same (sigma = 1), a zero sigma is refused (the residual divides by it), and values and
+error bars must pair up.  The arrays end up, flattened over all experiments, in ``sbm_project_desc``'s
+``row_data`` / ``row_sigma`` (include/sbm.h).
+"""
 import numpy as np
 
 
-class MeasurementABC(metaclass=ABCMeta):
-    @abstractmethod
+def _column(x, what):
+    a = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    if a.ndim != 1:
+        raise ValueError("%s must be one-dimensional" % what)
+    return a
+
+
+class MeasurementABC(object):
     def __init__(self, variable_name, measurement_value, measurement_std=None):
-        measurement_value = np.asarray(measurement_value, dtype=float)
-        if measurement_std is None:
-            # unweighted fit: sigma = 1 for every point (reference :12-13)
-            measurement_std = np.ones_like(measurement_value)
-        measurement_std = np.asarray(measurement_std, dtype=float)
-        if np.any(measurement_std == 0):
-            raise ValueError('Standard deviation of measurement cannot be 0')
-        if len(measurement_value) != len(measurement_std):
+        values = _column(measurement_value, 'measurement values')
+        std = np.ones_like(values) if measurement_std is None else _column(measurement_std, 'measurement std')
+        if std.shape != values.shape:
             raise ValueError('Length of Standard Deviation Array Not Equal to Length of Measurements')
-        self.variable_name = variable_name
-        self.values = measurement_value
-        self.std = measurement_std
+        if not np.all(std != 0):
+            raise ValueError('Standard deviation of measurement cannot be 0')
+        self.variable_name, self.values, self.std = variable_name, values, std
