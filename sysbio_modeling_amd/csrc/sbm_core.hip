@@ -480,10 +480,36 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   double* s_sde = s_B + (G > 0 ? G : 1);
   double* s_sds = s_sde + (G > 0 ? G : 1);
   double* s_red = s_sds + (G > 0 ? G : 1);  // [4]
-  double* s_dB = s_red + 4;                 // [G][q], then the partial sums [2][G][rpp][q]
+  // row tables staged once per block: every thread of pass A / B would otherwise chase them through
+  // global memory for each of its elements (a chain of dependent loads per element: the kernel was bound
+  // by that latency, not by HBM)
+  double* s_d = s_red + 4;                  // [R] measurement
+  double* s_sg = s_d + R;                   // [R] sigma
+  int* s_roff = (int*)(s_sg + R);           // [R] (e * n_t + tidx) * NV: offset of the row's time point in the vector's Y block
+  int* s_rexp = s_roff + R;                 // [R] experiment
+  int* s_rv0 = s_rexp + R;                  // [R] first entry of the row's variable list
+  int* s_rnv = s_rv0 + R;                   // [R] its length
+  int* s_rvar = s_rnv + R;                  // [R] first variable (the only one of a 'direct' mapping)
+  int* s_rsf = s_rvar + R;                  // [R] scale-factor group or -1
+  double* s_dB = (double*)(s_rsf + R);      // 6 R ints = 24 R bytes: 8-byte aligned.  [G][q], then the partial sums [2][G][rpp][q]
   __shared__ int s_bad;
 
   if (tid == 0) s_bad = 0;
+  for (int r = tid; r < R; r += blockDim.x) {
+    s_d[r] = a.row_data[r];
+    s_sg[r] = a.row_sigma[r];
+    s_rsf[r] = a.row_sf[r];
+    if (!a.sims_in) {
+      const int e = a.row_exp[r], v0 = a.row_var_off[r];
+      s_rexp[r] = e;
+      s_roff[r] = (e * a.n_t + a.row_tidx[r]) * a.NV;
+      s_rv0[r] = v0;
+      s_rnv[r] = a.row_var_off[r + 1] - v0;
+      s_rvar[r] = a.row_var_off[r + 1] > v0 ? a.row_vars[v0] : 0;
+    } else {
+      s_rexp[r] = 0; s_roff[r] = 0; s_rv0[r] = 0; s_rnv[r] = 0; s_rvar[r] = 0;
+    }
+  }
   __syncthreads();
   // status of the vector = worst status of its trajectories
   int st = 0, steps = 0;
@@ -503,9 +529,9 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
     if (a.sims_in) {
       s = a.sims_in[(size_t)v * R + r];
     } else {
-      const int e = a.row_exp[r];
-      const size_t base = (((size_t)v * E + e) * a.n_t + a.row_tidx[r]) * a.NV;
-      for (int k = a.row_var_off[r]; k < a.row_var_off[r + 1]; ++k) s += a.Y[base + a.row_vars[k]];
+      const double* Yb = a.Y + (size_t)v * E * a.n_t * a.NV + s_roff[r];
+      if (s_rnv[r] == 1) s = Yb[s_rvar[r]];
+      else for (int k = s_rv0[r]; k < s_rv0[r] + s_rnv[r]; ++k) s += Yb[a.row_vars[k]];
     }
     s_sim[r] = s;
     // NaN simulations -> inf rows; the log loss cannot take a non-positive simulation either
@@ -537,15 +563,15 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   for (int g = 0; g < G; ++g) {
     double sde = 0.0, sds = 0.0;
     for (int r = tid; r < R; r += blockDim.x) {
-      if (a.row_sf[r] == g) {
+      if (s_rsf[r] == g) {
         if (a.loss == SBM_LOSS_LOG_SQUARE) {
           // log_scale_factor.py:17-28: weights 1/(sigma/d)^2; log B = sum(w (log d - log s)) / sum(w)
-          const double w = (a.row_data[r] * a.row_data[r]) / (a.row_sigma[r] * a.row_sigma[r]);
-          sde += (log(a.row_data[r]) - log(s_sim[r])) * w;
+          const double w = (s_d[r] * s_d[r]) / (s_sg[r] * s_sg[r]);
+          sde += (log(s_d[r]) - log(s_sim[r])) * w;
           sds += w;
         } else {
-          const double w = 1.0 / (a.row_sigma[r] * a.row_sigma[r]);
-          sde += s_sim[r] * a.row_data[r] * w;
+          const double w = 1.0 / (s_sg[r] * s_sg[r]);
+          sde += s_sim[r] * s_d[r] * w;
           sds += s_sim[r] * s_sim[r] * w;
         }
       }
@@ -567,11 +593,11 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   for (int r = tid; r < RT; r += blockDim.x) {
     double res;
     if (r < R) {
-      const int g = a.row_sf[r];
+      const int g = s_rsf[r];
       const double B = g >= 0 ? s_B[g] : 1.0;
       const bool logrow = a.loss == SBM_LOSS_LOG_SQUARE && !(a.row_plain && a.row_plain[r]);
-      res = logrow ? (log(B * s_sim[r]) - log(a.row_data[r])) / a.row_sigma[r]
-                   : (B * s_sim[r] - a.row_data[r]) / a.row_sigma[r];
+      res = logrow ? (log(B * s_sim[r]) - log(s_d[r])) / s_sg[r]
+                   : (B * s_sim[r] - s_d[r]) / s_sg[r];
       s_res[r] = res;
     } else if (r < R + a.NPR) {
       const int k = r - R;
@@ -609,25 +635,35 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
     if (c >= q || rl >= rpp) continue;
     const double dth = a.Jm_in ? 1.0 : exp(th[c]);
     int gcur = -1;
+    int e_cur = -1, k0 = 0, k1 = 0, sc1 = -1;
     double jde = 0.0, jds = 0.0;
     for (int r = rl; r < R; r += rpp) {
       double jm = 0.0;
       if (a.Jm_in) {
         jm = a.Jm_in[((size_t)v * R + r) * q + c];
       } else {
-        const int e = a.row_exp[r];
-        const size_t base = ((((size_t)v * E + e) * a.n_t + a.row_tidx[r]) * a.NV) * a.NK;
-        for (int k = a.inv_ptr[e * (q + 1) + c]; k < a.inv_ptr[e * (q + 1) + c + 1]; ++k) {
-          const int sc = a.sens_col[a.inv_m[k]];
-          if (sc < 0) continue;
-          for (int kk = a.row_var_off[r]; kk < a.row_var_off[r + 1]; ++kk)
-            jm += a.S[base + (size_t)a.row_vars[kk] * a.NK + sc];
+        const int e = s_rexp[r];
+        if (e != e_cur) {   // rows are sorted by experiment: the column's model parameters change rarely
+          e_cur = e;
+          k0 = a.inv_ptr[e * (q + 1) + c];
+          k1 = a.inv_ptr[e * (q + 1) + c + 1];
+          sc1 = (k1 - k0 == 1) ? a.sens_col[a.inv_m[k0]] : -2;   // the common case: one model parameter per slot
+        }
+        const double* Sb = a.S + ((size_t)v * E * a.n_t * a.NV + s_roff[r]) * a.NK;
+        if (sc1 >= 0 && s_rnv[r] == 1) {
+          jm = Sb[(size_t)s_rvar[r] * a.NK + sc1];
+        } else if (sc1 != -1) {
+          for (int k = k0; k < k1; ++k) {
+            const int sc = a.sens_col[a.inv_m[k]];
+            if (sc < 0) continue;
+            for (int kk = s_rv0[r]; kk < s_rv0[r] + s_rnv[r]; ++kk) jm += Sb[(size_t)a.row_vars[kk] * a.NK + sc];
+          }
         }
         jm *= dth;
       }
       if (Jm) Jm[(size_t)r * q + c] = jm;
       if (Jv) Jv[(size_t)r * q + c] = jm;
-      const int g = a.row_sf[r];
+      const int g = s_rsf[r];
       if (g != gcur) {  // rows of one group are mostly consecutive: flush on change
         if (gcur >= 0) {
           s_part[((size_t)(0 * Gn + gcur) * rpp + rl) * q + c] += jde;
@@ -637,10 +673,10 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
       }
       if (g >= 0) {
         if (a.loss == SBM_LOSS_LOG_SQUARE) {  // log_scale_factor.py:30-36: sum J / (s (sigma/d)^2)
-          jde += jm * (a.row_data[r] * a.row_data[r]) / (a.row_sigma[r] * a.row_sigma[r] * s_sim[r]);
+          jde += jm * (s_d[r] * s_d[r]) / (s_sg[r] * s_sg[r] * s_sim[r]);
         } else {
-          const double w = 1.0 / (a.row_sigma[r] * a.row_sigma[r]);
-          jde += jm * a.row_data[r] * w;
+          const double w = 1.0 / (s_sg[r] * s_sg[r]);
+          jde += jm * s_d[r] * w;
           jds += jm * s_sim[r] * w;
         }
       }
@@ -674,7 +710,7 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
       const int r = (int)(i / q), c = (int)(i - (size_t)r * q);
       double val;
       if (r < R) {
-        const int g = a.row_sf[r];
+        const int g = s_rsf[r];
         val = Jv[i];
         if (a.loss == SBM_LOSS_LOG_SQUARE && !(a.row_plain && a.row_plain[r])) {
           // log_squared_loss_function.py:66-98: J/s (+ (dB/dtheta)/B for rows with a scale factor)
@@ -683,7 +719,7 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
         } else if (g >= 0) {
           val = s_B[g] * val + s_sim[r] * s_dB[g * q + c];
         }
-        if (!a.compat) val /= a.row_sigma[r];
+        if (!a.compat) val /= s_sg[r];
       } else if (r < R + a.NPR) {
         const int k = r - R;
         val = (!a.compat && a.prior_idx[k] == c) ? 1.0 / a.prior_sigma[k] : 0.0;
@@ -871,7 +907,8 @@ extern "C" int sbm_project_set_extrapolation(sbm_project* p, int32_t levels) {
 static int launch_assemble(const AssembleArgs& g, int V, hipStream_t s, const char* who) {
   const int Gn = g.G > 0 ? g.G : 1;
   const int cw_ = g.q < 256 ? g.q : 256, rpp_ = 256 / cw_;
-  const size_t lds = sizeof(double) * ((size_t)2 * g.R + 3 * Gn + 4 + (size_t)Gn * g.q + (size_t)2 * Gn * rpp_ * g.q);
+  const size_t lds = sizeof(double) * ((size_t)2 * g.R + 3 * Gn + 4 + (size_t)Gn * g.q + (size_t)2 * Gn * rpp_ * g.q) +
+                     sizeof(double) * 2 * (size_t)g.R + sizeof(int) * (6 * (size_t)g.R + 2);   // + the staged row tables
   if (lds > 160 * 1024) return sbm_fail(SBM_E_ARG, "%s: project too large for the assembly kernel (%zu B of LDS)", who, lds);
   if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_assemble, dim3(V), dim3(256), lds, s, g);
