@@ -37,17 +37,19 @@ typedef struct sbm_project sbm_project;
 /* integrators.  The reference always uses LSODA at rtol = atol = 1e-10
  * (model/ode_model.py:122-123,167-168); these are the GPU replacements. */
 enum {
-  SBM_RK4_FIXED = 0,        /* classic RK4, fixed step h0 between output times        */
-  SBM_DOPRI45 = 1,          /* Dormand-Prince 5(4), error control on state AND sens.   */
-  SBM_IMPLICIT_MIDPOINT = 2 /* stiff systems: implicit midpoint, fixed step h0, Newton with the
-                             * model's sparse LU; sensitivities = exact derivative of the scheme.
-                             * Second order with an h^2 error expansion (extrapolate two runs).
-                             * Needs n_vars <= 64 and n_sens <= 64. */
-  ,
-  SBM_IMPLICIT_MIDPOINT_GRADED = 3 /* the same with a graded first step: it is cut into 13 midpoint substeps
-                             * of sizes h0 * 2^-12, 2^-12, 2^-11, ..., 1/2.  For initial conditions off a
-                             * fast manifold -- the reference always starts from y = 0
-                             * (model/ode_model.py:151-152) -- whose initial layer no fixed step resolves. */
+  SBM_RK4_FIXED = 0,   /* classic RK4, fixed step h0 between output times                    */
+  SBM_DOPRI45 = 1,     /* Dormand-Prince 5(4), error control on state AND sensitivities      */
+  /* Stiff systems: implicit midpoint rule, fixed step h0, Newton iteration with the sparse LU
+   * the model generator worked out for the model's Jacobian pattern; the sensitivities are
+   * the exact derivative of the scheme (one linear solve per column with the matrix Newton
+   * just factored).  Second order, symmetric: the error expands in h^2, so two runs with
+   * step_mult 1 and 2 extrapolate to fourth order.  Needs n_vars <= 64 and n_sens <= 64.     */
+  SBM_IMPLICIT_MIDPOINT = 2,
+  /* The same with a graded first step, cut into 13 midpoint substeps of sizes
+   * h0 * 2^-12, 2^-12, 2^-11, ..., 1/2: for initial conditions off a fast manifold -- the
+   * reference always starts from y = 0 (model/ode_model.py:151-152) -- whose initial layer no
+   * fixed step resolves.                                                                     */
+  SBM_IMPLICIT_MIDPOINT_GRADED = 3
 };
 
 typedef struct sbm_integrator_opts {
