@@ -6,6 +6,7 @@ back to a CPU path when the device is missing."""
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -72,7 +73,7 @@ def test_plugins_export_plugin_abi():
     for name in ('simple', 'michaelis_menten', 'cascade20'):
         path = build.plugin_path(name)
         assert os.path.exists(path), "plugin %s not built (run __graft_entry__.build())" % path
-        out = os.popen("nm -D --defined-only %s" % path).read()
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
         assert 'sbm_plugin_info' in out and 'sbm_plugin_launch' in out
 
 
