@@ -388,6 +388,19 @@ class Project(object):
     def parameter_priors(self):
         return copy.deepcopy(self._parameter_priors)
 
+    def get_parameter_settings(self):
+        """Every parameter group with its settings and their index in the project vector (a copy;
+        reference :1064-1068)."""
+        import copy
+        return copy.deepcopy(self._project_param_idx)
+
+    def print_param_settings(self):
+        """Human-readable listing of the same (reference :1038-1062)."""
+        for p_group, slots in self._project_param_idx.items():
+            print("%s" % p_group)
+            for settings, idx in slots.items():
+                print("    %-30s theta[%d]" % (settings, idx))
+
     def get_ordered_project_params(self):
         names = [None] * self._n_project_params
         for p_group, slots in self._project_param_idx.items():
