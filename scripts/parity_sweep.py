@@ -1,0 +1,75 @@
+"""Parity sweep (evidence, not a test): the shipped sensitivity kernel against the SciPy restatement of the
+reference (odeint, rtol = atol = 1e-10, the reference's 1000-point grid) on the first N vectors of the
+configs[2] ensemble.  Writes the distribution of the error in units of the parity tolerance
+|gpu - ref| <= 1e-8 |ref| + 5e-9.
+
+    python scripts/parity_sweep.py [N] [out.json]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sysbio_modeling_amd import models_zoo
+from sysbio_modeling_amd.model import OdeModel
+from sysbio_modeling_amd.symbolic import zoo_model
+from oracle import odeint_oracle as oo
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    out_path = sys.argv[2] if len(sys.argv) > 2 else None
+    gm = zoo_model('cascade20')
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order)
+    _, P = models_zoo.cascade_ensemble(4096)
+    P = P[:n]
+    grid = np.linspace(0, 100, 1000)
+    idx = np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)
+    t_out = np.concatenate([[0.0], grid[idx]])
+    res = {}
+    for variant in ('row_group', 'row_lane', 'per_wave'):
+        S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, variant=variant)
+        ey, es = np.zeros(n), np.zeros(n)
+        t0 = time.time()
+        for v in range(n):
+            Sr, Yr = oo.calc_jacobian(gm, P[v], grid, use_c=True, return_states=True)
+            ey[v] = np.max(np.abs(Y[v, 1:] - Yr[idx]) / (1e-8 * np.abs(Yr[idx]) + 5e-9))
+            es[v] = np.max(np.abs(S[v, 1:] - Sr[idx]) / (1e-8 * np.abs(Sr[idx]) + 5e-9))
+        res[variant] = {"vectors": n, "state_err_tol_units": {"max": float(ey.max()), "median": float(np.median(ey)),
+                                                              "p99": float(np.percentile(ey, 99))},
+                        "sens_err_tol_units": {"max": float(es.max()), "median": float(np.median(es)),
+                                               "p99": float(np.percentile(es, 99))},
+                        "vectors_over_tolerance": int(((ey > 1) | (es > 1)).sum()),
+                        "oracle_seconds": round(time.time() - t0, 1)}
+        print(variant, res[variant], flush=True)
+        if variant == 'row_group':
+            # who is off on the worst vector?  A tight solution (DOP853, rtol 1e-13) of the augmented system decides.
+            from scipy.integrate import solve_ivp
+            w = int(np.argmax(es))
+            out = np.zeros(820)
+
+            def rhs(t, y):
+                gm.sens_model(y, t, out, P[w])
+                return out.copy()
+            sol = solve_ivp(rhs, (0.0, 100.0), np.zeros(820), method='DOP853', rtol=1e-13, atol=1e-15, t_eval=grid[idx])
+            St = sol.y.T[:, 20:]
+            Sr = oo.calc_jacobian(gm, P[w], grid, use_c=True)[idx]
+            tol = 1e-8 * np.abs(St) + 5e-9
+            res['worst_vector'] = {"index": w, "gpu_vs_scipy_tol_units": float(es[w]),
+                                   "gpu_vs_tight_tol_units": float(np.max(np.abs(S[w, 1:] - St) / tol)),
+                                   "scipy_vs_tight_tol_units": float(np.max(np.abs(Sr - St) / tol)),
+                                   "tight": "scipy.integrate.solve_ivp DOP853 rtol 1e-13 atol 1e-15"}
+            print('worst vector', res['worst_vector'], flush=True)
+    doc = {"what": "GPU (DOPRI45 rtol 1e-9 atol 1e-12) vs scipy.integrate.odeint (rtol = atol = 1e-10) on the first %d "
+                   "vectors of the configs[2] ensemble, 16 sampled rows x (20 states + 800 sensitivities)" % n,
+           "tolerance": "|gpu - ref| <= 1e-8 |ref| + 5e-9", "results": res}
+    if out_path:
+        with open(out_path, 'w') as fh:
+            json.dump(doc, fh, indent=1)
+
+
+if __name__ == '__main__':
+    main()
