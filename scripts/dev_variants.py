@@ -1,5 +1,5 @@
 """Developer timing: kernel variants on a random 17-species network (9 row classes)."""
-import os, sys, re
+import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

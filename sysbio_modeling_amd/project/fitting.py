@@ -10,7 +10,6 @@ a convergence count per iteration.
 """
 from __future__ import annotations
 
-import ctypes
 
 import numpy as np
 

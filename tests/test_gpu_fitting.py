@@ -1,14 +1,12 @@
 """Batched multi-start Levenberg-Marquardt against the reference's way of
 fitting: scipy.optimize.leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)
 (tests/test_Project.py:202-213, :352-357), which the same Project object also supports (batch of one)."""
-import ctypes
 import warnings
 
 import numpy as np
 import pytest
 from scipy.optimize import leastsq
 
-from tests import reference_cases as rc
 
 pytestmark = pytest.mark.gpu
 

@@ -9,7 +9,7 @@ import pandas as pd
 import pytest
 
 from tests import reference_cases as rc
-from tests.loss_cases import RowsOnlyOracle, lin_square_rows
+from tests.loss_cases import RowsOnlyOracle
 from sysbio_modeling_amd.project.loss_functions.squared_loss import (SquareLossFunction, LogSquareLossFunction,
                                                                     NormalizedSquareLossFunction)
 
