@@ -35,12 +35,16 @@
 // 1/x: v_rcp_f64 (~24 good bits on gfx950... refined by two Newton steps to < 1 ulp-ish).
 // The IEEE division sequence (div_scale/div_fmas/div_fixup) costs about twice as much
 // and the RHS of rate-law models is dominated by reciprocals.
+#ifndef SBM_RCP_NR
+#define SBM_RCP_NR 2
+#endif
 __device__ __forceinline__ double sbm_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(e, r, r);
-  e = fma(-x, r, 1.0);
-  r = fma(e, r, r);
+#pragma unroll
+  for (int it = 0; it < SBM_RCP_NR; ++it) {
+    const double e = fma(-x, r, 1.0);
+    r = fma(e, r, r);
+  }
   return r;
 }
 #define SBM_RCP(x) sbm_rcp(x)
