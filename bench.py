@@ -181,10 +181,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # rehearsal knob (not used by the driver): SBM_BENCH_REHEARSAL=1 runs every rank on GPU 0 over gloo, so
+    # that the multi-rank code path can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get('SBM_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
+        os.environ['LOCAL_RANK'] = '0'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from sysbio_modeling_amd import _lib
