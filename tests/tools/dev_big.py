@@ -2,7 +2,7 @@
 trajectory) runs through the per-wave kernels (three columns per lane, scratch spills) and agrees with odeint."""
 import os, sys, time, warnings
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.simplefilter('ignore')
 from sysbio_modeling_amd import models_zoo
 from sysbio_modeling_amd.symbolic import GeneratedModel

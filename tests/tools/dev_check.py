@@ -1,7 +1,7 @@
 """Developer smoke: first end-to-end run of the HIP path vs the oracle (not a test)."""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sysbio_modeling_amd.symbolic import zoo_model
 from sysbio_modeling_amd.model import OdeModel
 from sysbio_modeling_amd import models_zoo, _lib

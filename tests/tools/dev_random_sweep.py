@@ -2,9 +2,9 @@
 integrator, against odeint.  Prints one line per network; exits non-zero on the first disagreement."""
 import os, sys, warnings
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.simplefilter('ignore')
-src = open(os.path.join(os.path.dirname(__file__), '..', 'tests', 'test_gpu_user_models.py')).read()
+src = open(os.path.join(os.path.dirname(__file__), '..', 'test_gpu_user_models.py')).read()
 ns = {}
 exec("import numpy as np\n" + src[src.index("def _random_network"):src.index("@pytest.mark.parametrize('seed,n'")], ns)
 from sysbio_modeling_amd.symbolic import GeneratedModel

@@ -3,7 +3,7 @@ reference (odeint, rtol = atol = 1e-10, the reference's 1000-point grid) on the 
 configs[2] ensemble.  Writes the distribution of the error in units of the parity tolerance
 |gpu - ref| <= 1e-8 |ref| + 5e-9.
 
-    python scripts/parity_sweep.py [N] [out.json]
+    python tests/tools/parity_sweep.py [N] [out.json]
 """
 import json
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sysbio_modeling_amd import models_zoo
 from sysbio_modeling_amd.model import OdeModel
 from sysbio_modeling_amd.symbolic import zoo_model
