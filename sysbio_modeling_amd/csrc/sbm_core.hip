@@ -1119,9 +1119,9 @@ __global__ void __launch_bounds__(256) k_lm_step(LmArgs a) {
   const int v = blockIdx.x, tid = threadIdx.x, q = a.q, M = a.M;
   const int ld = q + 1;                      // padded leading dimension of the q x q matrices
   double* A = lm_smem;                       // [q][ld]  J^T J, then its Cholesky factor (lower)
-  double* H = A + (size_t)q * ld;            // [q][ld]  copy of J^T J for the predicted decrease
-  double* g = H + (size_t)q * ld;            // [q]      J^T r
-  double* x = g + q;                         // [q]      solution
+  double* dg = A + (size_t)q * ld;           // [q]      diag(J^T J)
+  double* g = dg + q;                        // [q]      J^T r
+  double* x = g + q;                         // [q]      right-hand side, then the solution
   double* T = x + q;                         // [LM_TILE][ld] row tile of J
   double* rt = T + (size_t)LM_TILE * ld;     // [LM_TILE]
   __shared__ int s_bad;
@@ -1169,18 +1169,16 @@ __global__ void __launch_bounds__(256) k_lm_step(LmArgs a) {
     }
   }
   __syncthreads();
-  for (int k = 0; k < n_own; ++k) {
-    A[oi[k] * ld + oj[k]] = acc[k];
-    H[oi[k] * ld + oj[k]] = acc[k];
-    H[oj[k] * ld + oi[k]] = acc[k];
-  }
+  for (int k = 0; k < n_own; ++k) A[oi[k] * ld + oj[k]] = acc[k];
   if (tid < q) g[tid] = gacc;
   __syncthreads();
   const double lam = a.lambda[v];
   if (tid < q) {
     const double d = A[tid * ld + tid];
+    dg[tid] = d;
     // Marquardt scaling; a column J never touches (d = 0) gets a unit pivot: delta_c = 0
     A[tid * ld + tid] = d > 0.0 ? d * (1.0 + lam) : 1.0;
+    x[tid] = -g[tid];
   }
   __syncthreads();
   bool bad = s_bad != 0 || !(lam >= 0.0);
@@ -1206,26 +1204,29 @@ __global__ void __launch_bounds__(256) k_lm_step(LmArgs a) {
     if (tid == 0) { a.pred[v] = 0.0; a.status[v] = 1; }
     return;
   }
-  // L y = -g ; L^T x = y   (q is small: one thread, the other 255 wait)
-  if (tid == 0) {
-    for (int i = 0; i < q; ++i) {
-      double s = -g[i];
-      for (int j = 0; j < i; ++j) s = fma(-A[i * ld + j], x[j], s);
-      x[i] = s / A[i * ld + i];
-    }
-    for (int i = q - 1; i >= 0; --i) {
-      double s = x[i];
-      for (int j = i + 1; j < q; ++j) s = fma(-A[j * ld + i], x[j], s);
-      x[i] = s / A[i * ld + i];
-    }
+  // L y = -g, then L^T x = y, column-oriented: one thread finishes x_i, all threads retire it from the
+  // remaining right-hand sides (two barriers per column instead of a serial O(q^2) chain on one thread)
+  for (int i = 0; i < q; ++i) {
+    if (tid == 0) x[i] /= A[i * ld + i];
+    __syncthreads();
+    const double xi = x[i];
+    for (int j = i + 1 + tid; j < q; j += 256) x[j] = fma(-A[j * ld + i], xi, x[j]);
+    __syncthreads();
   }
-  __syncthreads();
+  for (int i = q - 1; i >= 0; --i) {
+    if (tid == 0) x[i] /= A[i * ld + i];
+    __syncthreads();
+    const double xi = x[i];
+    for (int j = tid; j < i; j += 256) x[j] = fma(-A[i * ld + j], xi, x[j]);
+    __syncthreads();
+  }
+  // predicted decrease of 0.5 |r|^2 under the Gauss-Newton model, H = J^T J:  -g.d - 0.5 d^T H d  with
+  // (H + lambda D) d = -g  =>  d^T H d = -g.d - lambda sum D_i d_i^2   (D = diag(H), or 1 where it is 0)
   double part = 0.0;
   if (tid < q) {
     a.delta[(size_t)v * q + tid] = x[tid];
-    double hx = 0.0;
-    for (int j = 0; j < q; ++j) hx = fma(H[tid * ld + j], x[j], hx);
-    part = -x[tid] * (g[tid] + 0.5 * hx);
+    const double Di = dg[tid] > 0.0 ? dg[tid] : 0.0;
+    part = -0.5 * g[tid] * x[tid] + 0.5 * lam * Di * x[tid] * x[tid];
   }
   __shared__ double s_red[4];
   const double tot = block_sum(part, s_red);
@@ -1240,7 +1241,7 @@ extern "C" int sbm_lm_step(sbm_ctx* ctx, const double* J, const double* r, const
   SBM_HIP(hipSetDevice(ctx->device));
   LmArgs a{J, r, lambda, delta, pred, status, M, q};
   const size_t ld = (size_t)q + 1;
-  const size_t lds = sizeof(double) * (2 * q * ld + 2 * q + LM_TILE * ld + LM_TILE);
+  const size_t lds = sizeof(double) * (q * ld + 3 * q + LM_TILE * ld + LM_TILE);
   if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_lm_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_lm_step, dim3(V), dim3(256), lds, ctx->stream, a);
   SBM_HIP(hipGetLastError());
