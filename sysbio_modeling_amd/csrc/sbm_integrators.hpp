@@ -905,6 +905,12 @@ __global__ void __launch_bounds__(64) sbm_state_rows_kernel(sbm_kernel_args a) {
 // traffic of the row-lane kernel goes away.  Price: J_y coefficients are per-lane values now (LDS
 // table JYL instead of v_readlane scalars) and terms that cross a group boundary go through an LDS
 // halo (emit_rowgroup.py).  Still a 64-thread workgroup: wave-local LDS ordering, no barriers.
+//
+// Column chunks (M::RG_NCH > 1): the columns of S are coupled only through the state, so a trajectory with
+// more columns than one wavefront can hold in registers is cut into RG_NCH chunks of C*CPL columns;
+// blockIdx.y = chunk, each chunk integrates (state, its columns) on its own -- own error norm, own step
+// sequence, nothing exchanged.  Chunk 0 stores the state; status / step counts are combined with atomicMax
+// (the launcher zeroes them first).
 // ===========================================================================
 template <class M>
 struct SbmRowGroupShared {
@@ -934,6 +940,7 @@ struct RowGroupSystem {
   static constexpr int NH = M::RG_NHALO > 0 ? M::RG_NHALO : 1;
   SbmRowGroupShared<M>* sh;
   int lane, grp, cp;             // lane = grp*C + cp on the active lanes
+  int cbase;                     // first column of this wavefront's chunk
   bool active;                   // lane < G*C
   int cls;
   int yidx[M::RL_MAXYS];
@@ -1021,7 +1028,7 @@ struct RowGroupSystem {
         src = src >= G * C ? src - G * C : src;
         tot += __shfl(v, active ? src : lane, 64);
       }
-      const bool has_col = active && (cp + C * cc < M::NK);
+      const bool has_col = active && ((M::RG_NCH > 1 ? cbase : 0) + cp + C * cc < M::NK);
       m = fmaxf(m, has_col ? tot : 0.f);
     }
     const float x = (lane < M::NV) ? sbm_nan_to_inf(xsum) : 0.f;
@@ -1045,11 +1052,15 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   constexpr int MNV = M::NV, NK = M::NK;
   constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG, CPL = M::RG_CPL;
   constexpr int NE = Sys::NV, NVX = Sys::NVX, NPAD = Sh::NPAD;
-  static_assert(MNV <= 64 && G * C <= 64 && C * CPL <= 64 && C * CPL >= NK && NPAD >= MNV, "row-group layout");
+  constexpr int NCH = M::RG_NCH;
+  static_assert(MNV <= 64 && G * C <= 64 && C * CPL * NCH >= NK && C * CPL * (NCH - 1) < NK && NPAD >= MNV,
+                "row-group layout");
   __shared__ Sh sh;
   if ((int)blockIdx.x >= a.n_traj) return;
   const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int lane = threadIdx.x;
+  const int chunk = NCH > 1 ? (int)blockIdx.y : 0;
+  const int cbase = chunk * (C * CPL);
 
   constexpr int NROWS = Sh::NROWS;
   constexpr int LS = Sh::LS;
@@ -1064,6 +1075,7 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   sys.active = lane < G * C;
   sys.grp = sys.active ? lane / C : G;   // idle lanes form the all-padding group: zeros throughout
   sys.cp = lane - sys.grp * C;
+  sys.cbase = cbase;
   const bool has_row = lane < MNV;
   const int row = has_row ? lane : 0;
   sys.cls = has_row ? M::rl_class(row) : -1;
@@ -1079,8 +1091,13 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   }
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJP; ++s) {
-    const int ap = M::rl_apos(s, row);                        // row*64 + column; unused slots carry MNV*64
-    sys.apos[s] = (has_row && ap < MNV * 64) ? M::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1;
+    if constexpr (NCH == 1) {
+      const int ap = M::rl_apos(s, row);                      // row*64 + column; unused slots carry MNV*64
+      sys.apos[s] = (has_row && ap < MNV * 64) ? M::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1;
+    } else {
+      const int lc = M::rl_jpcol(s, row) - cbase;             // column within this chunk (unused slots: -1)
+      sys.apos[s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? M::rg_pos(row, lc) : RPG * LS + 1;
+    }
   }
   sys.a_lane = sh.A + CPL * lane;
   sys.jy_lane = sh.JYL + (sys.grp * RPG) * M::RG_JYS;
@@ -1102,7 +1119,7 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   for (int cc = 0; cc < CPL; ++cc)
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
-      const int grow = sys.grp * RPG + r, col = sys.cp + C * cc;
+      const int grow = sys.grp * RPG + r, col = cbase + sys.cp + C * cc;
       const bool valid = sys.active && grow < MNV && col < NK;
       z[0][r + RPG * cc] = (a.s0 && valid) ? a.s0[grow * NK + col] : 0.0;
     }
@@ -1111,13 +1128,13 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * MNV : nullptr;
   double* St = a.S ? a.S + (size_t)traj * a.n_t * MNV * NK : nullptr;
   auto store = [&](int io, const double (&zz)[1][NVX]) {
-    if (Yt && has_row) Yt[(size_t)io * MNV + lane] = zz[0][NE];
+    if (Yt && has_row && chunk == 0) Yt[(size_t)io * MNV + lane] = zz[0][NE];
     if (St) {
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc)
 #pragma unroll
         for (int r = 0; r < RPG; ++r) {
-          const int grow = sys.grp * RPG + r, col = sys.cp + C * cc;
+          const int grow = sys.grp * RPG + r, col = cbase + sys.cp + C * cc;
           if (sys.active && grow < MNV && col < NK) St[((size_t)io * MNV + grow) * NK + col] = zz[0][r + RPG * cc];
         }
     }
@@ -1128,9 +1145,16 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
 
   if (lane == 0) {
-    if (a.status) a.status[traj] = r.status;
-    if (a.n_steps) a.n_steps[traj] = r.n_acc;
-    if (a.n_reject) a.n_reject[traj] = r.n_rej;
+    if constexpr (NCH > 1) {
+      // worst status, most steps over the chunks (all non-negative; zeroed by the launcher)
+      if (a.status) atomicMax(a.status + traj, r.status);
+      if (a.n_steps) atomicMax(a.n_steps + traj, r.n_acc);
+      if (a.n_reject) atomicMax(a.n_reject + traj, r.n_rej);
+    } else {
+      if (a.status) a.status[traj] = r.status;
+      if (a.n_steps) a.n_steps[traj] = r.n_acc;
+      if (a.n_reject) a.n_reject[traj] = r.n_rej;
+    }
   }
 }
 
@@ -1169,6 +1193,8 @@ __device__ __forceinline__ double sbm_pick_tree(const double (&v)[N], int lane) 
 // bidiagonal forward substitution, not a dense 50x50 solve -- then solves its own right-hand side:
 // the Newton residual (picked apart again: lane i keeps delta_i) and its sensitivity column.
 // Fixed step h0 between output times like RK4; opts.rtol / atol are the Newton tolerances.
+// More than 64 columns: blockIdx.y = chunk of 64 columns, each wavefront repeating the (identical, fixed-step)
+// state iteration for its own columns; chunk 0 stores the state.
 // ===========================================================================
 template <class M>
 struct SbmImidShared {
@@ -1186,11 +1212,14 @@ template <class M>
 __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   constexpr int NV = M::NV, NK = M::NK;
   constexpr int MAXIT = 12;
-  static_assert(NV <= 64 && NK <= 64, "implicit midpoint kernel: one row and one column per lane");
+  constexpr int NCH = (NK + 63) / 64;
+  static_assert(NV <= 64, "implicit midpoint kernel: one row per lane");
   __shared__ SbmImidShared<M> sh;
   if ((int)blockIdx.x >= a.n_traj) return;
   const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int lane = threadIdx.x;
+  const int chunk = NCH > 1 ? (int)blockIdx.y : 0;
+  const int col = lane + 64 * chunk;       // this lane's column of S
   for (int i = lane; i < NV * 64 + 2; i += 64) sh.A[i] = 0.0;
   for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
   for (int i = lane; i < M::IM_NM + 2; i += 64) sh.MF[i] = 0.0;
@@ -1198,7 +1227,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   sh.G[lane] = 0.0;
 
   const bool has_row = lane < NV;
-  const bool has_col = lane < NK;
+  const bool has_col = col < NK;
   const int row = has_row ? lane : 0;
   const int cls = has_row ? M::rl_class(row) : -1;
   const double* P = a.P + (size_t)traj * M::NP;
@@ -1211,7 +1240,14 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJY; ++s) jyout[s] = has_row ? M::rl_jyout(s, row) : M::NJY + 1;
 #pragma unroll
-  for (int s = 0; s < M::RL_MAXJP; ++s) apos[s] = has_row ? M::rl_apos(s, row) : NV * 64 + 1;
+  for (int s = 0; s < M::RL_MAXJP; ++s) {
+    if constexpr (NCH == 1) {
+      apos[s] = has_row ? M::rl_apos(s, row) : NV * 64 + 1;
+    } else {
+      const int lc = M::rl_jpcol(s, row) - 64 * chunk;       // column within this chunk (unused slots: -1)
+      apos[s] = (has_row && lc >= 0 && lc < 64) ? row * 64 + lc : NV * 64 + 1;
+    }
+  }
   int mfpos[M::RL_MAXJY];
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJY; ++s) mfpos[s] = (M::IM_TRI && has_row) ? M::im_mfpos(s, row) : M::IM_NM + 1;
@@ -1227,7 +1263,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
 
   double z[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) z[i] = (a.s0 && has_col) ? a.s0[i * NK + lane] : 0.0;
+  for (int i = 0; i < NV; ++i) z[i] = (a.s0 && has_col) ? a.s0[i * NK + col] : 0.0;
   double y = (a.y0 && has_row) ? a.y0[lane] : 0.0;
 
   double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
@@ -1355,13 +1391,13 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
       for (int i = 0; i < NV; ++i) z[i] = __builtin_nan("");
       y = __builtin_nan("");
     }
-    if (Yt && has_row) Yt[(size_t)io * NV + lane] = y;
+    if (Yt && has_row && chunk == 0) Yt[(size_t)io * NV + lane] = y;
     if (St && has_col) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + lane] = z[i];
+      for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + col] = z[i];
     }
   }
-  if (lane == 0) {
+  if (lane == 0 && chunk == 0) {   // the state iteration, hence status and counts, is the same in every chunk
     if (a.status) a.status[traj] = status;
     if (a.n_steps) a.n_steps[traj] = n_acc;
     if (a.n_reject) a.n_reject[traj] = n_newton - n_acc;   // Newton iterations beyond one per step
@@ -1377,11 +1413,13 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
   if (a.n_traj <= 0) return (int)hipSuccess;
   if (a.opts.method == SBM_IMPLICIT_MIDPOINT || a.opts.method == SBM_IMPLICIT_MIDPOINT_GRADED) {
     // one trajectory per wave for both kinds (state only: S == NULL skips the column work)
-    if constexpr (M::NV <= 64 && M::NK <= 64) {
-      hipLaunchKernelGGL((sbm_imid_kernel<M>), dim3(a.n_traj), dim3(64), 0, stream, a);
+    if constexpr (M::NV <= 64) {
+      // state only: one wavefront; with sensitivities: one per chunk of 64 columns
+      const int nch = a.S ? (M::NK + 63) / 64 : 1;
+      hipLaunchKernelGGL((sbm_imid_kernel<M>), dim3(a.n_traj, nch), dim3(64), 0, stream, a);
       return (int)hipGetLastError();
     } else {
-      return (int)hipErrorInvalidConfiguration;   // needs one row and one column per lane
+      return (int)hipErrorInvalidConfiguration;   // needs one row per lane
     }
   }
   if (kind == SBM_KIND_SENS) {
@@ -1391,13 +1429,21 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     // and 17 rows: 1.6x faster than per-wave)
     constexpr bool kRowLaneOk = (M::NV <= 64 && M::NK <= 64);
     constexpr bool kRowLanePays = kRowLaneOk;
+    constexpr bool kRowGroupOk = (M::NV <= 64 && M::RG_OK);   // any number of columns: chunks of them
     const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
                          (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays);
     // row-group kernel: the row-lane kernel with the rows of a column split over several lanes,
     // when the emitter found a split that cuts the elements per lane (M::RG_OK)
-    if constexpr (kRowLaneOk && M::RG_OK) {
-      if (a.opts.variant == SBM_VARIANT_ROW_GROUP || (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays)) {
-        dim3 grid(a.n_traj), block(64);
+    if constexpr (kRowGroupOk) {
+      if (a.opts.variant == SBM_VARIANT_ROW_GROUP || a.opts.variant == SBM_VARIANT_AUTO) {
+        dim3 grid(a.n_traj, M::RG_NCH), block(64);
+        if constexpr (M::RG_NCH > 1) {
+          hipError_t e = hipSuccess;
+          if (a.status) e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+          if (e == hipSuccess && a.n_steps) e = hipMemsetAsync(a.n_steps, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+          if (e == hipSuccess && a.n_reject) e = hipMemsetAsync(a.n_reject, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+          if (e != hipSuccess) return (int)e;
+        }
         if (a.opts.method == SBM_DOPRI45)
           hipLaunchKernelGGL((sbm_sens_rowgroup_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
         else

@@ -26,33 +26,71 @@ Every lane owns private slots: the 64 lanes of a wave access consecutive CPL*8-b
 conflicts, one ds_read_b128 per local row for CPL = 2), slots of idle lanes and padded rows are
 never written and stay zero.
 
+COLUMN CHUNKS.  The sensitivity columns of a trajectory are coupled only through the state
+(S' = J_y(y) S + J_p, column by column), so a trajectory whose columns do not fit one wavefront --
+more than 64 parameters, or more elements per lane than the register file holds -- is cut into NCH
+chunks of C*CPL columns, each integrated by its own wavefront together with a private copy of the
+state (blockIdx.y = chunk).  No data is exchanged between the chunks; each runs its own step-size
+control on (state, its columns), so all of them meet the tolerance, on step sequences of their own.
+
 ``plan`` decides whether the form pays at all (RG_OK); the integrator falls back to the
-row-lane kernel otherwise.
+row-lane kernel (or, beyond 64 columns, to the per-wave kernel) otherwise.
 """
 from __future__ import annotations
 
 
-def plan(n, nk, max_lanes=64):
-    """(G, C, CPL, RPG) minimising the elements per lane, or None when splitting rows does not
-    reduce them by at least 20 %."""
-    if n < 2 or nk < 1 or n > max_lanes:
-        return None
+REG_ELEMS = 15      # elements per lane up to which DOPRI45's stage vectors fit 256 registers (two waves per SIMD)
+AGPR_ELEMS = 34     # ... up to which they fit 512 (one wave per SIMD, v_accvgpr traffic); beyond: scratch
+STATE_COST = 5      # work of the per-chunk state evaluation, in elements per lane
+
+
+def _best_split(n, ncols, g_min, max_lanes=64):
+    """(elems, G, C, CPL, RPG) with the fewest elements per lane for ``ncols`` columns on one wavefront."""
     best = None
-    for G in range(2, 9):
+    for G in range(g_min, 9):
         C = max_lanes // G
         if C < 1:
             break
-        CPL = -(-nk // C)
-        C = -(-nk // CPL)          # balance the columns over the CPL slots
+        CPL = -(-ncols // C)
+        C = -(-ncols // CPL)       # balance the columns over the CPL slots
         RPG = -(-n // G)
-        if (G - 1) * RPG >= n:     # an empty last group: a smaller G does the same
+        if G > 1 and (G - 1) * RPG >= n:     # an empty last group: a smaller G does the same
             continue
         elems = RPG * CPL
         if best is None or elems < best[0]:
             best = (elems, G, C, CPL, RPG)
-    if best is None or best[0] > 0.8 * n:
+    return best
+
+
+def _cost(elems, nch):
+    spill = 1.0 if elems <= REG_ELEMS else (1.6 if elems <= AGPR_ELEMS else 4.0)
+    return nch * (elems + STATE_COST) * spill
+
+
+def plan(n, nk, max_lanes=64):
+    """(G, C, CPL, RPG, NCH): lanes (g, c') of NCH column chunks.  None when the row-lane kernel does as
+    well: one chunk, and splitting the rows cuts the elements per lane by less than 20 %."""
+    if n < 2 or nk < 1 or n > max_lanes:
         return None
-    return best[1:]
+    best = None
+    for nch in range(1, 33):
+        if nch > nk:
+            break
+        ncols = -(-nk // nch)
+        if nch > 1 and (nch - 1) * ncols >= nk:
+            continue                                   # an empty last chunk
+        sp = _best_split(n, ncols, 2 if nch == 1 else 1, max_lanes)
+        if sp is None:
+            continue
+        key = (_cost(sp[0], nch), nch)
+        if best is None or key < best[0]:
+            best = (key, sp, nch)
+    if best is None:
+        return None
+    (_, sp, nch) = best
+    if nch == 1 and nk <= max_lanes and sp[0] > 0.8 * n:
+        return None
+    return sp[1:] + (nch,)
 
 
 def layout(spec, d):
@@ -61,7 +99,7 @@ def layout(spec, d):
     p = plan(n, nk)
     if p is None:
         return None
-    G, C, CPL, RPG = p
+    G, C, CPL, RPG, NCH = p
     pattern = []                       # per global row: {cyclic offset: (e_idx, m)}
     for i in range(n):
         pattern.append({(m - i) % n: (e_idx, m) for e_idx, m in d.jy_rows[i]})
@@ -103,7 +141,7 @@ def layout(spec, d):
         rel_to_k = {t['rel']: k for k, t in enumerate(terms[r])}
         for s, (e_idx, m) in enumerate(d.jy_rows[i]):
             jypos[s][i] = i * jys + rel_to_k[(m - i) % n]
-    return dict(G=G, C=C, CPL=CPL, RPG=RPG, LS=64 * CPL, terms=terms, hsrc=hsrc,
+    return dict(G=G, C=C, CPL=CPL, RPG=RPG, NCH=NCH, LS=64 * CPL, terms=terms, hsrc=hsrc,
                 publish=sorted(publish), jys=jys, jypos=jypos, max_jy=max_jy, n_pad=n_pad)
 
 
@@ -129,6 +167,7 @@ def emit_members(spec, d, lay):
         return ["  // ---- row-group form: does not pay for this model ----",
                 "  static constexpr bool RG_OK = false;",
                 "  static constexpr int RG_G = 1, RG_C = 64, RG_CPL = 1, RG_RPG = NV, RG_JYS = 1, RG_NHALO = 0, RG_LS = 64;",
+                "  static constexpr int RG_NCH = 1;",
                 "  __device__ __forceinline__ static int rg_jypos(int, int) { return 0; }",
                 "  __device__ __forceinline__ static int rg_hsrc(int, int) { return 0; }",
                 "  __device__ __forceinline__ static int rg_pos(int row, int col) { return row * 64 + col; }",
@@ -143,8 +182,9 @@ def emit_members(spec, d, lay):
          "  static constexpr bool RG_OK = true;",
          "  static constexpr int RG_G = %d, RG_C = %d, RG_CPL = %d, RG_RPG = %d, RG_JYS = %d, RG_NHALO = %d;"
          % (G, C, CPL, RPG, jys, nh),
+         "  static constexpr int RG_NCH = %d;  // column chunks (wavefronts) per trajectory, C*CPL columns each" % lay['NCH'],
          "  static constexpr int RG_LS = %d;   // local-row stride of the A / H tables (doubles): [r][lane][cc]" % LS,
-         "  // position of (row, column) in A / H",
+         "  // position of (row, column of the chunk) in A / H",
          "  __device__ __forceinline__ static int rg_pos(int row, int col) {",
          "    return (row % RG_RPG) * RG_LS + RG_CPL * ((row / RG_RPG) * RG_C + col % RG_C) + col / RG_C;",
          "  }",

@@ -108,6 +108,9 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
     constexpr int NH = M::RG_NHALO > 0 ? M::RG_NHALO : 1;
     constexpr int LS = M::RG_LS, ZPOS = RPG * LS;
     static double A[RPG * LS + 2], H[RPG * LS + 4], JYL[NROWS * JYS + 2];
+    // one pass per column chunk (on the device: one wavefront each, blockIdx.y)
+    for (int chunk = 0; chunk < M::RG_NCH; ++chunk) {
+    const int cbase = chunk * C * CPL;
     for (double& v : A) v = 0.0;
     for (double& v : H) v = 0.0;
     for (double& v : JYL) v = 0.0;
@@ -119,8 +122,8 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
       for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
       M::class_dispatch(M::rl_class(row), t, ys, ps, f, jy, jp);
       for (int s = 0; s < M::RL_MAXJP; ++s) {
-        const int ap = M::rl_apos(s, row);
-        A[ap < N * 64 ? M::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1] = jp[s];
+        const int lc = M::rl_jpcol(s, row) - cbase;
+        A[(lc >= 0 && lc < C * CPL && lc + cbase < K) ? M::rg_pos(row, lc) : RPG * LS + 1] = jp[s];
       }
       for (int s = 0; s < M::RL_MAXJY; ++s) {
         const int jpz = M::rg_jypos(s, row);
@@ -134,7 +137,7 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
       const int g = active ? lane / C : G, cp = lane - g * C;
       for (int cc = 0; cc < CPL; ++cc)
         for (int r = 0; r < RPG; ++r) {
-          const int grow = g * RPG + r, col = cp + C * cc;
+          const int grow = g * RPG + r, col = cbase + cp + C * cc;
           z[lane][r + RPG * cc] = (active && grow < N && col < K) ? y[N + grow * K + col] : 0.0;
         }
       M::publish_rowgroup(H + CPL * lane, z[lane]);
@@ -152,10 +155,11 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
       M::apply_rowgroup(acol, coef, H, hoff, z[lane], dz[lane]);
       for (int cc = 0; cc < CPL; ++cc)
         for (int r = 0; r < RPG; ++r) {
-          const int grow = g * RPG + r, col = cp + C * cc;
+          const int grow = g * RPG + r, col = cbase + cp + C * cc;
           if (active && grow < N && col < K) yout[N + grow * K + col] = dz[lane][r + RPG * cc];
           else if (dz[lane][r + RPG * cc] != 0.0) return -2;   // padding must stay exactly zero
         }
+    }
     }
     return 0;
   }

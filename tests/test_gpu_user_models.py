@@ -74,26 +74,39 @@ def test_model_text_with_laws_and_fixed_parameter(tmp_path):
 
 
 def test_more_sensitivity_columns_than_lanes():
-    """35 species, 70 parameters: 71 columns of [y | S] do not fit 64 lanes, so the per-wave kernel
-    runs two columns per lane (CPL = 2) and the row-lane / row-group forms do not apply."""
+    """35 species, 70 parameters: more columns than a wavefront has lanes.  The row-group kernel cuts them into
+    chunks (one wavefront each, every chunk with its own copy of the state and its own step control); the
+    per-wave kernel runs two columns per lane; the implicit kernel runs one wavefront per 64 columns.  All
+    agree with LSODA."""
     from sysbio_modeling_amd import models_zoo
     from sysbio_modeling_amd.symbolic import GeneratedModel
     from sysbio_modeling_amd.model import OdeModel
     gm = GeneratedModel(models_zoo.cascade_spec(35, name='cascade35'))
-    assert gm.n_sens == 70
+    assert gm.n_sens == 70 and 'RG_OK = true' in gm.hip_source and 'RG_NCH = 1;' not in gm.hip_source
     m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='cascade35')
     rng = np.random.default_rng(9)
     P = models_zoo.cascade_nominal_params(35)[None, :] * np.exp(0.3 * rng.standard_normal((3, 70)))
     t = np.linspace(0, 60.0, 1000)
     idx = np.array([0, 300, 999])
-    S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True)
-    assert m.last_info['status'].tolist() == [0, 0, 0]
     Yr, Sr = _odeint_ref(gm, P[1], t)
-    assert parity_err(Y[1], Yr[idx]) <= 1.0 and parity_err(S[1], Sr[idx]) <= 1.0
+    steps = {}
+    for variant in ('auto', 'row_group', 'per_wave'):
+        S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant)
+        assert m.last_info['status'].tolist() == [0, 0, 0]
+        assert parity_err(Y[1], Yr[idx]) <= 1.0 and parity_err(S[1], Sr[idx]) <= 1.0, variant
+        steps[variant] = m.last_info['n_steps'].copy()
+    assert np.array_equal(steps['auto'], steps['row_group'])           # AUTO picks the chunked row-group kernel
     S_rk = m.calc_jacobian_batch(P, t[idx], method='rk4', n_steps=8192)
     assert np.allclose(S_rk, S, rtol=1e-7, atol=1e-9)
-    with pytest.raises(Exception):
-        m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=64)   # needs n_sens <= 64
+    S_im = m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=8192, extrapolate=1,
+                                 rtol=1e-11, atol=1e-13)
+    assert m.last_info['status'].tolist() == [0, 0, 0]
+    assert parity_err(S_im[1], Sr[idx]) <= 1.0
+    # initial sensitivities reach the right chunk: S(t0) = S0 comes back unchanged at the first output time
+    S0 = rng.standard_normal((35, 70))
+    y0 = np.concatenate([np.full(35, 0.3), S0.ravel()])
+    S_ic = m.calc_jacobian_batch(P[:1], np.array([0.0, 1.0]), init_conditions=y0)
+    assert np.array_equal(S_ic[0, 0], S0.ravel())
 
 
 def _random_network(seed, n):

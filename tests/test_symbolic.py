@@ -141,8 +141,8 @@ def test_hip_text_equals_python_and_c_on_host(name, tmp_path):
         out = np.zeros(n + n * k)
         rc_ = lib.h_sens_rhs_rowgroup(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp),
                                       p.ctypes.data_as(dp))
-        # a single row cannot be split; 50 rows x 50 columns already fill the lanes
-        assert rc_ == (-1 if name in ('simple', 'stiff50') else 0)
+        # a single row cannot be split (stiff50: five chunks of ten columns, nine rows per lane)
+        assert rc_ == (-1 if name == 'simple' else 0)
         if rc_ == 0:
             assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
         ref_s = np.zeros(n)
@@ -231,12 +231,44 @@ def test_rowgroup_form_of_an_irregular_network(tmp_path):
 
 def test_rowgroup_plan():
     from sysbio_modeling_amd.symbolic.emit_rowgroup import plan
-    assert plan(20, 40) == (3, 20, 2, 7)       # cascade20: 14 elements on 60 lanes instead of 20 on 40
+    assert plan(20, 40) == (3, 20, 2, 7, 1)    # cascade20: 14 elements on 60 lanes instead of 20 on 40
     assert plan(1, 2) is None                  # nothing to split
     assert plan(70, 10) is None                # more rows than lanes: no row-lane form at all
-    assert plan(30, 64) is None                # every lane already carries a column
-    G, C, CPL, RPG = plan(30, 20)
-    assert G * C <= 64 and C * CPL >= 20 and G * RPG >= 30 and RPG * CPL <= 0.8 * 30
+    G, C, CPL, RPG, NCH = plan(30, 20)
+    assert NCH == 1 and G * C <= 64 and C * CPL >= 20 and G * RPG >= 30 and RPG * CPL <= 0.8 * 30
+    # more columns than one wavefront holds in registers: chunks of columns, one wavefront each
+    for n, nk in ((30, 64), (40, 80), (50, 50), (64, 200), (5, 300)):
+        G, C, CPL, RPG, NCH = plan(n, nk)
+        assert G * C <= 64 and G * RPG >= n and (G - 1) * RPG < n
+        assert C * CPL * NCH >= nk and C * CPL * (NCH - 1) < nk       # every chunk holds a column
+        assert RPG * CPL <= 15                                       # DOPRI45's stage vectors fit 256 registers
+    assert plan(40, 80)[4] > 1 and plan(50, 50)[4] > 1
+
+
+def test_rowgroup_column_chunks_on_host(tmp_path):
+    """A 40-state / 80-parameter cascade (beyond one column per lane): the chunked row-group form, emulated
+    lane by lane and chunk by chunk, equals the Python emitter's sensitivity RHS."""
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    gm = GeneratedModel(models_zoo.cascade_spec(40, name='cascade40'))
+    n, k = gm.n_vars, gm.n_sens
+    assert (n, k) == (40, 80) and 'RG_NCH = 5' in gm.hip_source
+    hdr = tmp_path / 'cascade40.hpp'
+    hdr.write_text(gm.hip_source)
+    so = str(tmp_path / 'h_cascade40.so')
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-DSBM_MODEL_HEADER="%s"' % hdr,
+                           os.path.join(HERE, 'support', 'host_model_harness.cpp'), '-o', so])
+    lib = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        y = rng.uniform(0.05, 2.0, n + n * k)
+        p = rng.uniform(0.05, 2.0, len(gm.param_order))
+        ref = np.zeros(n + n * k)
+        gm.sens_model(y, 0.0, ref, p)
+        out = np.zeros(n + n * k)
+        assert lib.h_sens_rhs_rowgroup(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp),
+                                       p.ctypes.data_as(dp)) == 0
+        assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
 
 
 @pytest.mark.parametrize('name', ZOO_NAMES + ('irregular',))
