@@ -17,7 +17,8 @@ SBM_RK4_FIXED = 0
 SBM_DOPRI45 = 1
 SBM_IMPLICIT_MIDPOINT = 2
 SBM_IMPLICIT_MIDPOINT_GRADED = 3
-STATUS_NAMES = {0: 'ok', 1: 'max_steps', 2: 'non_finite', 3: 'step_underflow', 4: 'newton_fail'}
+STATUS_NAMES = {0: 'ok', 1: 'max_steps', 2: 'non_finite', 3: 'step_underflow', 4: 'newton_fail',
+                5: 'tolerance_not_reached'}
 
 
 class SbmError(RuntimeError):

@@ -26,6 +26,7 @@ import numpy as np
 
 from . import utils
 from .. import _lib
+from .. import _control
 from .loss_functions.squared_loss import SquareLossFunction
 
 
@@ -585,7 +586,57 @@ class Project(object):
         want : any of 'residuals', 'sims', 'sf', 'norms', 'status', 'n_steps' and, with
             ``jacobian=True``, 'jacobian', 'model_jacobian', 'gradient', 'sf_gradient'.
         Returns a dict of numpy arrays (torch CUDA tensors if ``thetas`` was one).
+
+        ``method='implicit_controlled'`` integrates with the implicit midpoint rule under global error
+        control and ``method='auto'`` with DOPRI45 first and that for the vectors DOPRI45 gives up on
+        (stiff ones) -- the control loops of ``_control.py``; the result then also carries 'stiff' (V,)
+        bool.  Every other method is one device call.
         """
+        o = dict(self.integrator_options)
+        o.update(integrator_overrides)
+        method = str(o.get('method', 'dopri45')).lower()
+        if method not in _control.IMPLICIT_CONTROLLED + _control.AUTO:
+            return self._evaluate_once(thetas, jacobian, want, **integrator_overrides)
+        import torch
+        th, as_torch = self._theta_dev(thetas)
+        V = th.shape[0]
+        compare = ['sims'] + (['jacobian'] if jacobian else [])
+        rtol, atol = float(o.get('rtol', 1e-9)), float(o.get('atol', 1e-12))
+        keep = {k: v for k, v in o.items() if k in ('variant',)}
+
+        def split(res):
+            st, ns = res.pop('status'), res.pop('n_steps')
+            return res, st, ns
+
+        def controlled(idx):
+            sub_th = th[torch.as_tensor(idx, device=th.device, dtype=torch.long)]
+
+            def run(sub, n):
+                t = sub_th[torch.as_tensor(sub, device=th.device, dtype=torch.long)]
+                return split(self._evaluate_once(t, jacobian, want, method='implicit_midpoint_graded', n_steps=n,
+                                                 extrapolate=1, rtol=max(1e-2 * rtol, 1e-13),
+                                                 atol=max(1e-2 * atol, 1e-300), max_steps=0, **keep))
+            return _control.controlled_doubling(run, len(idx), compare, rtol, atol,
+                                                n0=int(o.get('n_steps', 0) or 256),
+                                                max_doublings=int(o.get('max_doublings', 7)))
+        if method in _control.IMPLICIT_CONTROLLED:
+            out, st, steps, _ = controlled(np.arange(V))
+            stiff = np.ones(V, dtype=bool)
+        else:
+            budget = int(o.get('max_steps') or 0) or 50000
+            out, st, steps, stiff = _control.with_stiff_fallback(
+                lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=budget,
+                                                  rtol=rtol, atol=atol, extrapolate=0, **keep)),
+                controlled, V)
+        out['status'] = torch.as_tensor(st, dtype=torch.int32, device=th.device)
+        out['n_steps'] = torch.as_tensor(np.minimum(steps, 2 ** 31 - 1), dtype=torch.int32, device=th.device)
+        out['stiff'] = torch.as_tensor(stiff, device=th.device)
+        if as_torch:
+            return out
+        return {k: v.cpu().numpy() for k, v in out.items()}
+
+    def _evaluate_once(self, thetas, jacobian=False, want=('residuals',), **integrator_overrides):
+        """One device call: all vectors with one integrator setting."""
         import torch
         proj = self._device()
         lib = _lib.load_library()

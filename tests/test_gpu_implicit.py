@@ -150,6 +150,109 @@ def test_project_on_the_stiff_model_with_extrapolation(gpu_models, golden):
     assert parity_err(out0['sims'][0], np.concatenate([Yr[0][:, species[k]] for k in order])) > 50.0
 
 
+def test_controlled_implicit_needs_no_step_count(gpu_models, golden):
+    """method='implicit_controlled': the step count is found by doubling until two successive Richardson
+    extrapolants agree (sysbio_modeling_amd/_control.py).  With default options the result meets the parity
+    tolerance against the reference's LSODA golden; every vector reports the level it stopped at."""
+    m = gpu_models('stiff50')
+    g = golden('stiff50_ref.npz')
+    P, Yr, Sr = g['P'], g['Y'], g['S']
+    t_out = _from_zero(g['t'][g['idx']])
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled')
+    info = m.last_info
+    assert info['status'].tolist() == [0, 0, 0]
+    assert np.all(info['levels'] >= 1) and np.all(info['n_steps'] >= 3 * 256)
+    # against a much finer solution of the same scheme (three runs, h^2 and h^4 terms cancelled): the returned
+    # values are within the requested tolerance (1e-9 relative to max(|x|, 1e-3 max|x|)) ...
+    St, Yt = m.calc_jacobian_batch(P, t_out, return_states=True, n_steps=8192, extrapolate=2,
+                                   method='implicit_midpoint_graded', rtol=1e-11, atol=1e-14)
+    for got, fine in ((Y, Yt), (S, St)):
+        sc = 1e-9 * np.maximum(np.abs(fine), 1e-3 * np.abs(fine).reshape(3, -1).max(axis=1)[:, None, None]) + 1e-12
+        assert np.max(np.abs(got - fine) / sc) <= 2.0          # (the fine solution is itself good to ~1 unit)
+    # ... and LSODA's golden values (themselves good to ~1e-8) are met as closely as the fine solution meets them
+    assert parity_err(Y[:, 1:], Yr) <= 1.0
+    assert parity_err(S[:, 1:], Sr) <= max(1.0, 1.05 * parity_err(St[:, 1:], Sr))
+    # a looser tolerance stops earlier and is less accurate, but about within ITS tolerance (an estimate, not a bound)
+    S2 = m.calc_jacobian_batch(P, t_out, method='implicit_controlled', rtol=1e-5, atol=1e-8)
+    assert np.all(m.last_info['levels'] < info['levels'])
+    assert np.max(np.abs(S2[:, 1:] - Sr) / (1e-5 * np.maximum(np.abs(Sr), 1e-3 * np.abs(Sr).max()) + 1e-8)) <= 2.0
+    # a tolerance out of reach within the allowed doublings is reported, with the finest result returned
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Y3 = m.simulate_batch(P[:1], t_out, method='implicit_controlled', rtol=1e-9, n_steps=16, max_doublings=2)
+    assert m.last_info['status'].tolist() == [5] and np.all(np.isfinite(Y3))
+
+
+def test_auto_method_switches_stiff_vectors_to_the_implicit_integrator(gpu_models, golden):
+    """method='auto' is what LSODA's method switching is to the reference: DOPRI45 with a step budget, then the
+    controlled implicit integrator for the vectors that exhausted it.  Two vectors of the SAME model: the
+    golden (stiffness ratio 1e7: DOPRI45 would need ~1e7 steps) and one with all rates within a decade."""
+    from oracle import odeint_oracle as oo
+    from sysbio_modeling_amd.symbolic import zoo_model
+    m = gpu_models('stiff50')
+    gm = zoo_model('stiff50')
+    g = golden('stiff50_ref.npz')
+    t_out = _from_zero(g['t'][g['idx']])
+    mild = g['P'][0].copy()
+    mild[:50] = 10.0 ** np.linspace(0.0, 1.0, 50)
+    P = np.stack([g['P'][0], mild])
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method='auto', max_steps=20000)
+    info = m.last_info
+    assert info['status'].tolist() == [0, 0] and info['stiff'].tolist() == [True, False]
+    assert parity_err(Y[0, 1:], g['Y'][0]) <= 1.0 and parity_err(S[0, 1:], g['S'][0]) <= 1.0
+    Yr = oo.simulate(gm, mild, g['t'], use_c=True)[g['idx']]
+    assert parity_err(Y[1, 1:], Yr) <= 1.0
+    S1 = m.calc_jacobian_batch(P[1:], t_out)                 # plain DOPRI45: the very same numbers
+    assert np.array_equal(S[1], S1[0])
+    # state-only path, and a model that is not stiff at all: nothing switches
+    Ys = m.simulate_batch(P, t_out, method='auto', max_steps=20000)
+    assert m.last_info['stiff'].tolist() == [True, False] and parity_err(Ys[0, 1:], g['Y'][0]) <= 1.0
+    c = gpu_models('cascade20')
+    from sysbio_modeling_amd import models_zoo
+    _, Pc = models_zoo.cascade_ensemble(8)
+    tc = np.linspace(0, 100, 5)
+    Sa = c.calc_jacobian_batch(Pc, tc, method='auto')
+    assert not c.last_info['stiff'].any()
+    assert np.array_equal(Sa, c.calc_jacobian_batch(Pc, tc))
+
+
+def test_project_auto_method_on_the_stiff_model(gpu_models, golden):
+    """Project.evaluate_batch(method='auto'): residual rows and the model Jacobian of a stiff vector come from
+    the controlled implicit integrator, those of a mild vector from DOPRI45, in one call."""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    m = gpu_models('stiff50')
+    g = golden('stiff50_ref.npz')
+    P, Yr, Sr = g['P'], g['Y'], g['S'].reshape(3, 16, 50, 50)
+    species = (0, 10, 49)
+    ms = [TimecourseMeasurement('s%02d' % v, Yr[0][:, v] * 1.3, models_zoo.STIFF_MEASURE_TIMES.copy(),
+                                0.05 * np.abs(Yr[0][:, v]) + 0.01) for v in species]
+    exp = Experiment('E', ms, fixed_parameters={'b%d' % i: 0.5 for i in range(50)})
+    proj = Project(m, [exp], {'Global': ['a%d' % i for i in range(50)], 'Fixed': ['b%d' % i for i in range(50)]},
+                   {('s%02d' % v): ('direct', v) for v in species}, reference_compat=False)
+    names = list(m.param_order)
+    cols = [proj.get_param_index('a%d' % j, 'Global') for j in range(50)]
+    theta = np.zeros((2, 50))
+    theta[0, cols] = np.log(P[0, [names.index('a%d' % j) for j in range(50)]])
+    theta[1, cols] = np.log(10.0) * np.linspace(0.0, 1.0, 50)
+    out = proj.evaluate_batch(theta, jacobian=True, want=('jacobian', 'model_jacobian'), method='auto',
+                              max_steps=20000)
+    assert out['status'].tolist() == [0, 0] and out['stiff'].tolist() == [True, False]
+    sims_ref = np.concatenate([Yr[0][:, v] for v in species])
+    assert parity_err(out['sims'][0], sims_ref) <= 1.0
+    Jm_ref = np.concatenate([Sr[0][:, v, :] for v in species]) * P[0][None, :50]
+    assert parity_err(out['model_jacobian'][0][:, cols], Jm_ref) <= 1.0
+    plain = proj.evaluate_batch(theta[1:], jacobian=True, want=('jacobian', 'model_jacobian'))
+    assert np.array_equal(out['jacobian'][1], plain['jacobian'][0])
+    assert np.array_equal(out['residuals'][1], plain['residuals'][0])
+    # the single-vector API of the reference takes the method from the project's options
+    proj.integrator_options.update(method='auto', max_steps=20000)
+    r = proj.residuals(theta[0])
+    assert np.allclose(r, out['residuals'][0], rtol=1e-9, atol=1e-11)
+
+
 STIFF_MOTIF = """
 #*! Parameters Start
     k_on = p[0]
