@@ -807,47 +807,58 @@ __global__ void __launch_bounds__(64) sbm_sens_rowlane_kernel(sbm_kernel_args a)
 // ===========================================================================
 template <class M>
 struct StateRowSystem {
-  static constexpr int NV = 0;           // no column rows: the lane's state component is the "extra" element
-  static constexpr int NVX = 1;
+  static constexpr int NV = 0;           // no column rows: the lane's state components are the "extra" elements
+  static constexpr int RPL = (M::NV + 63) / 64;   // state rows per lane: lane, lane + 64, ...
+  static constexpr int NVX = RPL;
   static constexpr int CPL = 1;
   static constexpr int NCS = 1;
   static constexpr bool kUniform = true;
   __device__ __forceinline__ static constexpr int col_of(int, int) { return 0; }
-  double* Y;                     // [64] in LDS: stage state, one component per lane
-  int lane, cls;
-  int yidx[M::RL_MAXYS];
-  double ps[M::RL_MAXPS];
+  double* Y;                     // [64 * RPL] in LDS: stage state, one component per (lane, r)
+  int lane;
+  int cls[RPL];
+  int yidx[RPL][M::RL_MAXYS];
+  double ps[RPL][M::RL_MAXPS];
 
-  struct Pending { double ys[M::RL_MAXYS]; };
-  struct Token { double f; };
-  __device__ __forceinline__ Pending issue(double, const double (&z)[1][1]) const {
+  struct Pending { double ys[RPL][M::RL_MAXYS]; };
+  struct Token { double f[RPL]; };
+  __device__ __forceinline__ Pending issue(double, const double (&z)[1][NVX]) const {
     Pending p;
-    Y[lane] = z[0][0];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) Y[lane + 64 * r] = z[0][r];
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[s] = Y[yidx[s]];
+    for (int r = 0; r < RPL; ++r)
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[r][s] = Y[yidx[r][s]];
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     return p;
   }
   __device__ __forceinline__ Token eval(const Pending& p, double t) const {
     Token k;
-    double jy[M::RL_MAXJY], jp[M::RL_MAXJP];   // dead: the compiler drops the Jacobian arithmetic
-    k.f = 0.0;
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+    for (int r = 0; r < RPL; ++r) {
+      double jy[M::RL_MAXJY], jp[M::RL_MAXJP];   // dead: the compiler drops the Jacobian arithmetic
+      k.f[r] = 0.0;
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
-    M::class_dispatch(cls, t, p.ys, ps, k.f, jy, jp);
-    k.f = cls >= 0 ? k.f : 0.0;
+      for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
+      M::class_dispatch(cls[r], t, p.ys[r], ps[r], k.f[r], jy, jp);
+      k.f[r] = cls[r] >= 0 ? k.f[r] : 0.0;
+    }
     return k;
   }
-  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][1]) const { dz[0][0] = k.f; }
-  __device__ __forceinline__ void finish(const Token&, double, const double (&)[1][1], double (&)[1][1]) const {}
-  __device__ __forceinline__ void rhs(double t, const double (&z)[1][1], double (&dz)[1][1]) const {
+  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][NVX]) const {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) dz[0][r] = k.f[r];
+  }
+  __device__ __forceinline__ void finish(const Token&, double, const double (&)[1][NVX], double (&)[1][NVX]) const {}
+  __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
     extra_out(eval(issue(t, z), t), dz);
   }
   __device__ __forceinline__ float norm(const float (&)[1], float xsum) const {
-    const float x = (lane < M::NV) ? sbm_nan_to_inf(xsum) : 0.f;
+    const float x = (lane < M::NV) ? sbm_nan_to_inf(xsum) : 0.f;   // rows beyond NV hold zeros throughout
     return sqrtf(sbm_wave_sumf(x) * (1.0f / M::NV));
   }
   __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
@@ -856,32 +867,37 @@ struct StateRowSystem {
 template <class M, int METHOD>
 __global__ void __launch_bounds__(64) sbm_state_rows_kernel(sbm_kernel_args a) {
   using Sys = StateRowSystem<M>;
-  static_assert(M::NV <= 64, "one state component per lane");
-  __shared__ double Ysh[64];
+  constexpr int RPL = Sys::RPL;
+  __shared__ double Ysh[64 * RPL];
   if ((int)blockIdx.x >= a.n_traj) return;
   const int traj = blockIdx.x;
   const int lane = threadIdx.x;
-  Ysh[lane] = 0.0;
   Sys sys;
   sys.Y = Ysh;
   sys.lane = lane;
-  const bool has_row = lane < M::NV;
-  const int row = has_row ? lane : 0;
-  sys.cls = has_row ? M::rl_class(row) : -1;
   const double* P = a.P + (size_t)traj * M::NP;
+  double z[1][RPL];
 #pragma unroll
-  for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[s] = M::rl_ys(s, row);
+  for (int r = 0; r < RPL; ++r) {
+    Ysh[lane + 64 * r] = 0.0;
+    const bool has_row = lane + 64 * r < M::NV;
+    const int row = has_row ? lane + 64 * r : 0;
+    sys.cls[r] = has_row ? M::rl_class(row) : -1;
 #pragma unroll
-  for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[s] = P[M::rl_ps(s, row)];
+    for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[r][s] = M::rl_ys(s, row);
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[r][s] = P[M::rl_ps(s, row)];
+    z[0][r] = (a.y0 && has_row) ? a.y0[row] : 0.0;
+  }
   __syncthreads();
   const int goff = a.grid_off ? a.grid_off[traj] : 0;
   const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
   const double* tg = a.t_out + goff;
-  double z[1][1];
-  z[0][0] = (a.y0 && has_row) ? a.y0[lane] : 0.0;
   double* Yt = a.Y + (size_t)traj * a.n_t * M::NV;
-  auto store = [&](int io, const double (&zz)[1][1]) {
-    if (has_row) Yt[(size_t)io * M::NV + lane] = zz[0][0];
+  auto store = [&](int io, const double (&zz)[1][RPL]) {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r)
+      if (lane + 64 * r < M::NV) Yt[(size_t)io * M::NV + lane + 64 * r] = zz[0][r];
   };
   SbmTrajOut r;
   if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
@@ -920,7 +936,8 @@ struct SbmRowGroupShared {
   static constexpr int NROWS = NPAD + M::RG_RPG;
   static constexpr int LS = M::RG_LS;    // A / H are [local row][lane][cc]; element (i, j) at M::rg_pos(i, j)
   static constexpr int ZPOS = M::RG_RPG * LS;   // a slot of H that stays zero (absent halo terms)
-  double Y[64];                          // stage state, one component per row lane
+  static constexpr int RPL = (M::NV + 63) / 64;   // state rows per lane (rows lane, lane + 64, ...)
+  double Y[64 * RPL];                    // stage state, one component per (row lane, r)
   alignas(16) double JYL[NROWS * M::RG_JYS + 2];   // J_y coefficients [row][term] (+ spare slot)
   alignas(16) double A[M::RG_RPG * LS + 2];        // J_p entries (+ spare slot); idle / padded slots stay 0
   alignas(16) double H[M::RG_RPG * LS + 4];        // published rows of the stage vector (+ zero slot)
@@ -933,7 +950,8 @@ template <class M, bool EARLY>
 struct RowGroupSystem {
   static constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG;
   static constexpr int NV = M::RG_RPG * M::RG_CPL;   // elements of S this lane integrates
-  static constexpr int NVX = NV + 1;                 // + this lane's own state component
+  static constexpr int RPL = (M::NV + 63) / 64;      // state rows this lane evaluates: lane, lane + 64, ...
+  static constexpr int NVX = NV + RPL;               // + this lane's own state component(s)
   static constexpr int CPL = 1;
   static constexpr int NCS = M::RG_CPL;
   __device__ __forceinline__ static constexpr int col_of(int, int i) { return i / M::RG_RPG; }
@@ -942,11 +960,11 @@ struct RowGroupSystem {
   int lane, grp, cp;             // lane = grp*C + cp on the active lanes
   int cbase;                     // first column of this wavefront's chunk
   bool active;                   // lane < G*C
-  int cls;
-  int yidx[M::RL_MAXYS];
-  double ps[M::RL_MAXPS];
-  int jypos[M::RL_MAXJY];
-  int apos[M::RL_MAXJP];
+  int cls[RPL];
+  int yidx[RPL][M::RL_MAXYS];
+  double ps[RPL][M::RL_MAXPS];
+  int jypos[RPL][M::RL_MAXJY];
+  int apos[RPL][M::RL_MAXJP];
   const double* a_lane;
   const double* jy_lane;
   double* h_lane;
@@ -955,34 +973,43 @@ struct RowGroupSystem {
   __device__ __forceinline__ static void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 
   struct Token {
-    double f;
+    double f[RPL];
     double acol[EARLY ? NV : 1], coef[EARLY ? RPG * M::RG_JYS : 1];
   };
-  struct Pending { double ys[M::RL_MAXYS]; };
+  struct Pending { double ys[RPL][M::RL_MAXYS]; };
   __device__ __forceinline__ Pending issue(double /*t*/, const double (&z)[1][NVX]) const {
     Pending p;
-    sh->Y[lane] = z[0][NV];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) sh->Y[lane + 64 * r] = z[0][NV + r];
     lds_order();
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[s] = sh->Y[yidx[s]];
+    for (int r = 0; r < RPL; ++r)
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[r][s] = sh->Y[yidx[r][s]];
     lds_order();
     return p;
   }
   __device__ __forceinline__ Token eval(const Pending& p, double t) const {
     Token k;
-    double jy[M::RL_MAXJY], jp[M::RL_MAXJP];
-    k.f = 0.0;
+    double jy[RPL][M::RL_MAXJY], jp[RPL][M::RL_MAXJP];
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+    for (int r = 0; r < RPL; ++r) {
+      k.f[r] = 0.0;
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
-    M::class_dispatch(cls, t, p.ys, ps, k.f, jy, jp);
-    k.f = cls >= 0 ? k.f : 0.0;   // lanes without a row come out of the select chain with the last class's value
+      for (int s = 0; s < M::RL_MAXJY; ++s) jy[r][s] = 0.0;
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXJP; ++s) jp[r][s] = 0.0;
+      M::class_dispatch(cls[r], t, p.ys[r], ps[r], k.f[r], jy[r], jp[r]);
+      k.f[r] = cls[r] >= 0 ? k.f[r] : 0.0;   // lanes without a row come out of the select chain with the last class's value
+    }
     lds_order();
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
+    for (int r = 0; r < RPL; ++r) {
 #pragma unroll
-    for (int s = 0; s < M::RL_MAXJY; ++s) sh->JYL[jypos[s]] = jy[s];
+      for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[r][s]] = jp[r][s];
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXJY; ++s) sh->JYL[jypos[r][s]] = jy[r][s];
+    }
     lds_order();
     if constexpr (EARLY) {
       M::load_rowgroup(a_lane, jy_lane, k.acol, k.coef);
@@ -1008,7 +1035,10 @@ struct RowGroupSystem {
 #pragma unroll
     for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
   }
-  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][NVX]) const { dz[0][NV] = k.f; }
+  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][NVX]) const {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) dz[0][NV + r] = k.f[r];
+  }
   __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
     const Token k = eval(issue(t, z), t);
     extra_out(k, dz);
@@ -1044,7 +1074,7 @@ template <class M, int METHOD>
 // stage vectors to fit: 2*(RPG*CPL + 1)*7 + operands <= 256 holds up to 15 elements (cascade20: 14 + 1).
 // Larger shares get the whole register file (one wave per SIMD) rather than spill.
 #ifndef SBM_RG_MIN_WAVES
-#define SBM_RG_MIN_WAVES ((M::RG_RPG * M::RG_CPL + 1 <= 15 || METHOD == SBM_RK4_FIXED) ? 2 : 1)
+#define SBM_RG_MIN_WAVES ((M::RG_RPG * M::RG_CPL + (M::NV + 63) / 64 <= 15 || METHOD == SBM_RK4_FIXED) ? 2 : 1)
 #endif
 __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel(sbm_kernel_args a) {
   using Sys = RowGroupSystem<M, METHOD == SBM_RK4_FIXED>;
@@ -1053,8 +1083,8 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG, CPL = M::RG_CPL;
   constexpr int NE = Sys::NV, NVX = Sys::NVX, NPAD = Sh::NPAD;
   constexpr int NCH = M::RG_NCH;
-  static_assert(MNV <= 64 && G * C <= 64 && C * CPL * NCH >= NK && C * CPL * (NCH - 1) < NK && NPAD >= MNV,
-                "row-group layout");
+  constexpr int RPL = Sys::RPL;
+  static_assert(G * C <= 64 && C * CPL * NCH >= NK && C * CPL * (NCH - 1) < NK && NPAD >= MNV, "row-group layout");
   __shared__ Sh sh;
   if ((int)blockIdx.x >= a.n_traj) return;
   const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
@@ -1067,7 +1097,8 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   for (int i = lane; i < RPG * LS + 2; i += 64) sh.A[i] = 0.0;
   for (int i = lane; i < RPG * LS + 4; i += 64) sh.H[i] = 0.0;
   for (int i = lane; i < NROWS * M::RG_JYS + 2; i += 64) sh.JYL[i] = 0.0;
-  sh.Y[lane] = 0.0;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) sh.Y[lane + 64 * r] = 0.0;
 
   Sys sys;
   sys.sh = &sh;
@@ -1076,27 +1107,30 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   sys.grp = sys.active ? lane / C : G;   // idle lanes form the all-padding group: zeros throughout
   sys.cp = lane - sys.grp * C;
   sys.cbase = cbase;
-  const bool has_row = lane < MNV;
-  const int row = has_row ? lane : 0;
-  sys.cls = has_row ? M::rl_class(row) : -1;
   const double* P = a.P + (size_t)traj * M::NP;
 #pragma unroll
-  for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[s] = M::rl_ys(s, row);
+  for (int r = 0; r < RPL; ++r) {
+    const bool has_row = lane + 64 * r < MNV;
+    const int row = has_row ? lane + 64 * r : 0;
+    sys.cls[r] = has_row ? M::rl_class(row) : -1;
 #pragma unroll
-  for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[s] = P[M::rl_ps(s, row)];
+    for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[r][s] = M::rl_ys(s, row);
 #pragma unroll
-  for (int s = 0; s < M::RL_MAXJY; ++s) {
-    const int jp_ = M::rg_jypos(s, row);
-    sys.jypos[s] = (has_row && jp_ < NPAD * M::RG_JYS) ? jp_ : NROWS * M::RG_JYS + 1;   // else: spare slot
-  }
+    for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[r][s] = P[M::rl_ps(s, row)];
 #pragma unroll
-  for (int s = 0; s < M::RL_MAXJP; ++s) {
-    if constexpr (NCH == 1) {
-      const int ap = M::rl_apos(s, row);                      // row*64 + column; unused slots carry MNV*64
-      sys.apos[s] = (has_row && ap < MNV * 64) ? M::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1;
-    } else {
-      const int lc = M::rl_jpcol(s, row) - cbase;             // column within this chunk (unused slots: -1)
-      sys.apos[s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? M::rg_pos(row, lc) : RPG * LS + 1;
+    for (int s = 0; s < M::RL_MAXJY; ++s) {
+      const int jp_ = M::rg_jypos(s, row);
+      sys.jypos[r][s] = (has_row && jp_ < NPAD * M::RG_JYS) ? jp_ : NROWS * M::RG_JYS + 1;   // else: spare slot
+    }
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) {
+      if constexpr (NCH == 1 && RPL == 1) {
+        const int ap = M::rl_apos(s, row);                      // row*64 + column; unused slots carry MNV*64
+        sys.apos[r][s] = (has_row && ap < MNV * 64) ? M::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1;
+      } else {
+        const int lc = M::rl_jpcol(s, row) - cbase;             // column within this chunk (unused slots: -1)
+        sys.apos[r][s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? M::rg_pos(row, lc) : RPG * LS + 1;
+      }
     }
   }
   sys.a_lane = sh.A + CPL * lane;
@@ -1123,12 +1157,17 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
       const bool valid = sys.active && grow < MNV && col < NK;
       z[0][r + RPG * cc] = (a.s0 && valid) ? a.s0[grow * NK + col] : 0.0;
     }
-  z[0][NE] = (a.y0 && has_row) ? a.y0[lane] : 0.0;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) z[0][NE + r] = (a.y0 && lane + 64 * r < MNV) ? a.y0[lane + 64 * r] : 0.0;
 
   double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * MNV : nullptr;
   double* St = a.S ? a.S + (size_t)traj * a.n_t * MNV * NK : nullptr;
   auto store = [&](int io, const double (&zz)[1][NVX]) {
-    if (Yt && has_row && chunk == 0) Yt[(size_t)io * MNV + lane] = zz[0][NE];
+    if (Yt && chunk == 0) {
+#pragma unroll
+      for (int r = 0; r < RPL; ++r)
+        if (lane + 64 * r < MNV) Yt[(size_t)io * MNV + lane + 64 * r] = zz[0][NE + r];
+    }
     if (St) {
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc)
@@ -1429,7 +1468,7 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     // and 17 rows: 1.6x faster than per-wave)
     constexpr bool kRowLaneOk = (M::NV <= 64 && M::NK <= 64);
     constexpr bool kRowLanePays = kRowLaneOk;
-    constexpr bool kRowGroupOk = (M::NV <= 64 && M::RG_OK);   // any number of columns: chunks of them
+    constexpr bool kRowGroupOk = M::RG_OK;   // any number of columns (chunks of them), up to four rows per lane
     const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
                          (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays);
     // row-group kernel: the row-lane kernel with the rows of a column split over several lanes,
@@ -1466,7 +1505,7 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     else hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
   } else {
     // one trajectory per wave until the chip is full of lane-per-trajectory waves anyway
-    constexpr bool kRowsOk = (M::NV <= 64);
+    constexpr bool kRowsOk = (M::NV <= 256);   // up to four state rows per lane
     if constexpr (kRowsOk) {
       if (a.n_traj < 65536 && a.opts.variant != SBM_VARIANT_PER_WAVE) {
         dim3 grid(a.n_traj), block(64);

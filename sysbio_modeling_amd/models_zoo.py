@@ -72,10 +72,11 @@ CASCADE_N = 20
 CASCADE_K_FEEDBACK = 1.0
 
 
-def cascade_spec(n=CASCADE_N, name=None):
+def cascade_spec(n=CASCADE_N, name=None, fixed=()):
     """x_0' = k_0/(1 + x_{n-1}/K) - d_0 x_0 ;  x_i' = k_i x_{i-1}/(1 + x_{i-1}) - d_i x_i.
 
-    Parameter order: k_0..k_{n-1}, d_0..d_{n-1}.  K = 1 is a literal constant.
+    Parameter order: k_0..k_{n-1}, d_0..d_{n-1}.  K = 1 is a literal constant.  ``fixed``: names of
+    parameters without a sensitivity column.
     """
     xs = [Symbol('x%d' % i) for i in range(n)]
     ks = [Symbol('k%d' % i) for i in range(n)]
@@ -87,7 +88,7 @@ def cascade_spec(n=CASCADE_N, name=None):
     # Float(1.0) factors print as 1.0*..., fold them
     eq = OrderedDict((v, sympy.nsimplify(e, rational=True)) for v, e in eq.items())
     return ModelSpec(name=name or ('cascade%d' % n), variables=[str(x) for x in xs],
-                     params=[str(k) for k in ks] + [str(d) for d in ds], equations=eq)
+                     params=[str(k) for k in ks] + [str(d) for d in ds], equations=eq, fixed=list(fixed))
 
 
 def cascade_nominal_params(n=CASCADE_N):

@@ -33,6 +33,10 @@ chunks of C*CPL columns, each integrated by its own wavefront together with a pr
 state (blockIdx.y = chunk).  No data is exchanged between the chunks; each runs its own step-size
 control on (state, its columns), so all of them meet the tolerance, on step sequences of their own.
 
+MORE THAN 64 STATE VARIABLES.  The state lives one component per lane; beyond 64 rows a lane takes rows
+lane, lane + 64, ... (up to four), evaluating their classes one after the other.  Nothing else changes:
+the tables are indexed by global row.
+
 ``plan`` decides whether the form pays at all (RG_OK); the integrator falls back to the
 row-lane kernel (or, beyond 64 columns, to the per-wave kernel) otherwise.
 """
@@ -41,13 +45,14 @@ from __future__ import annotations
 
 REG_ELEMS = 15      # elements per lane up to which DOPRI45's stage vectors fit 256 registers (two waves per SIMD)
 AGPR_ELEMS = 34     # ... up to which they fit 512 (one wave per SIMD, v_accvgpr traffic); beyond: scratch
+MAX_ROWS_PER_LANE = 4
 STATE_COST = 5      # work of the per-chunk state evaluation, in elements per lane
 
 
 def _best_split(n, ncols, g_min, max_lanes=64):
     """(elems, G, C, CPL, RPG) with the fewest elements per lane for ``ncols`` columns on one wavefront."""
     best = None
-    for G in range(g_min, 9):
+    for G in range(g_min, 9 if n <= max_lanes else 17):
         C = max_lanes // G
         if C < 1:
             break
@@ -62,18 +67,20 @@ def _best_split(n, ncols, g_min, max_lanes=64):
     return best
 
 
-def _cost(elems, nch):
-    spill = 1.0 if elems <= REG_ELEMS else (1.6 if elems <= AGPR_ELEMS else 4.0)
-    return nch * (elems + STATE_COST) * spill
+def _cost(elems, nch, rpl=1):
+    spill = 1.0 if elems + rpl <= REG_ELEMS + 1 else (1.6 if elems <= AGPR_ELEMS else 4.0)
+    return nch * (elems + STATE_COST * rpl) * spill
 
 
 def plan(n, nk, max_lanes=64):
     """(G, C, CPL, RPG, NCH): lanes (g, c') of NCH column chunks.  None when the row-lane kernel does as
-    well: one chunk, and splitting the rows cuts the elements per lane by less than 20 %."""
-    if n < 2 or nk < 1 or n > max_lanes:
+    well (one chunk, and splitting the rows cuts the elements per lane by less than 20 %) or the model has
+    more than 4 x 64 state variables."""
+    if n < 2 or nk < 1 or n > MAX_ROWS_PER_LANE * max_lanes:
         return None
+    rpl = -(-n // max_lanes)           # state rows per lane: rows lane, lane + 64, ...
     best = None
-    for nch in range(1, 33):
+    for nch in range(1, 65):
         if nch > nk:
             break
         ncols = -(-nk // nch)
@@ -82,7 +89,7 @@ def plan(n, nk, max_lanes=64):
         sp = _best_split(n, ncols, 2 if nch == 1 else 1, max_lanes)
         if sp is None:
             continue
-        key = (_cost(sp[0], nch), nch)
+        key = (_cost(sp[0], nch, rpl), nch)
         if best is None or key < best[0]:
             best = (key, sp, nch)
     if best is None:

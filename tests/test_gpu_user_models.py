@@ -109,6 +109,39 @@ def test_more_sensitivity_columns_than_lanes():
     assert np.array_equal(S_ic[0, 0], S0.ravel())
 
 
+def test_more_state_variables_than_lanes():
+    """70 species: a lane of the row kernels carries two state rows (lane, lane + 64).  18 of the 140 parameters
+    have sensitivity columns (the rest are 'fixed': keeps the per-wave comparison kernel small).  Row-group
+    (AUTO), per-wave and LSODA agree; so does the state-only path (state-rows kernel, two rows per lane)."""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    from sysbio_modeling_amd.model import OdeModel
+    n = 70
+    fixed = ['d%d' % i for i in range(n)] + ['k%d' % i for i in range(n) if i % 4]
+    gm = GeneratedModel(models_zoo.cascade_spec(n, name='cascade70f', fixed=fixed))
+    assert gm.n_vars == 70 and gm.n_sens == 18 and 'RG_OK = true' in gm.hip_source
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='cascade70f')
+    rng = np.random.default_rng(4)
+    P = models_zoo.cascade_nominal_params(n)[None, :] * np.exp(0.3 * rng.standard_normal((3, 2 * n)))
+    t = np.linspace(0, 60.0, 1000)
+    idx = np.array([0, 300, 999])
+    Yr, Sr = _odeint_ref(gm, P[2], t)
+    res = {}
+    for variant in ('auto', 'per_wave'):
+        S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant)
+        assert m.last_info['status'].tolist() == [0, 0, 0]
+        assert parity_err(Y[2], Yr[idx]) <= 1.0 and parity_err(S[2], Sr[idx]) <= 1.0, variant
+        res[variant] = (S, m.last_info['n_steps'].copy())
+    assert not np.array_equal(res['auto'][0], res['per_wave'][0])      # two kernels, not one
+    Ys = m.simulate_batch(P, t[idx])
+    assert m.last_info['status'].tolist() == [0, 0, 0] and parity_err(Ys[2], Yr[idx]) <= 1.0
+    S_rk = m.calc_jacobian_batch(P, t[idx], method='rk4', n_steps=8192)
+    assert np.allclose(S_rk, res['auto'][0], rtol=1e-7, atol=1e-9)
+    y0 = np.concatenate([0.2 + 0.01 * np.arange(n), rng.standard_normal(n * 18)])
+    S_ic, Y_ic = m.calc_jacobian_batch(P[:1], np.array([0.0, 1.0]), init_conditions=y0, return_states=True)
+    assert np.array_equal(Y_ic[0, 0], y0[:n]) and np.array_equal(S_ic[0, 0], y0[n:])
+
+
 def _random_network(seed, n):
     """Random rate-law network: every species is produced from one or two others (mass action or
     saturating), degraded linearly, some with product inhibition; bounded by construction."""

@@ -233,11 +233,12 @@ def test_rowgroup_plan():
     from sysbio_modeling_amd.symbolic.emit_rowgroup import plan
     assert plan(20, 40) == (3, 20, 2, 7, 1)    # cascade20: 14 elements on 60 lanes instead of 20 on 40
     assert plan(1, 2) is None                  # nothing to split
-    assert plan(70, 10) is None                # more rows than lanes: no row-lane form at all
+    assert plan(257, 3) is None                # more than four rows per lane
     G, C, CPL, RPG, NCH = plan(30, 20)
     assert NCH == 1 and G * C <= 64 and C * CPL >= 20 and G * RPG >= 30 and RPG * CPL <= 0.8 * 30
     # more columns than one wavefront holds in registers: chunks of columns, one wavefront each
-    for n, nk in ((30, 64), (40, 80), (50, 50), (64, 200), (5, 300)):
+    # ... and more state variables than lanes: up to four rows per lane
+    for n, nk in ((30, 64), (40, 80), (50, 50), (64, 200), (5, 300), (70, 140), (70, 10), (128, 256)):
         G, C, CPL, RPG, NCH = plan(n, nk)
         assert G * C <= 64 and G * RPG >= n and (G - 1) * RPG < n
         assert C * CPL * NCH >= nk and C * CPL * (NCH - 1) < nk       # every chunk holds a column
@@ -245,16 +246,18 @@ def test_rowgroup_plan():
     assert plan(40, 80)[4] > 1 and plan(50, 50)[4] > 1
 
 
-def test_rowgroup_column_chunks_on_host(tmp_path):
-    """A 40-state / 80-parameter cascade (beyond one column per lane): the chunked row-group form, emulated
-    lane by lane and chunk by chunk, equals the Python emitter's sensitivity RHS."""
+@pytest.mark.parametrize('n_states,n_chunks', [(40, 5), (70, 12)])
+def test_rowgroup_column_chunks_on_host(tmp_path, n_states, n_chunks):
+    """Cascades beyond one column per lane (40 states / 80 parameters) and beyond one state row per lane (70 /
+    140): the chunked row-group form, emulated lane by lane and chunk by chunk, equals the Python emitter's
+    sensitivity RHS."""
     from sysbio_modeling_amd.symbolic import GeneratedModel
-    gm = GeneratedModel(models_zoo.cascade_spec(40, name='cascade40'))
+    gm = GeneratedModel(models_zoo.cascade_spec(n_states, name='cascade%d' % n_states))
     n, k = gm.n_vars, gm.n_sens
-    assert (n, k) == (40, 80) and 'RG_NCH = 5' in gm.hip_source
-    hdr = tmp_path / 'cascade40.hpp'
+    assert (n, k) == (n_states, 2 * n_states) and 'RG_NCH = %d;' % n_chunks in gm.hip_source
+    hdr = tmp_path / 'cascade.hpp'
     hdr.write_text(gm.hip_source)
-    so = str(tmp_path / 'h_cascade40.so')
+    so = str(tmp_path / 'h_cascade.so')
     subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-DSBM_MODEL_HEADER="%s"' % hdr,
                            os.path.join(HERE, 'support', 'host_model_harness.cpp'), '-o', so])
     lib = ctypes.CDLL(so)

@@ -20,7 +20,7 @@ Sr = oo.calc_jacobian(gm, P[0], t, use_c=True)[idx]
 Yr = oo.simulate(gm, P[0], t, use_c=True)[idx]
 m.calc_jacobian_batch(P[:2], t[idx])     # load / warm up
 cases = [('dopri45', 'auto', {}), ('dopri45', 'per_wave', {}), ('rk4', 'auto', {'n_steps': 4096})]
-if n <= 64:
+if n <= 64:  # implicit kernel: one state row per lane
     cases.append(('implicit_midpoint', 'auto', {'n_steps': 4096, 'extrapolate': 1, 'rtol': 1e-11, 'atol': 1e-13}))
 for meth, variant, kw in cases:
     t0 = time.time()
