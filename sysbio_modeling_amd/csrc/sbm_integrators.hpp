@@ -1469,12 +1469,16 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     constexpr bool kRowLaneOk = (M::NV <= 64 && M::NK <= 64);
     constexpr bool kRowLanePays = kRowLaneOk;
     constexpr bool kRowGroupOk = M::RG_OK;   // any number of columns (chunks of them), up to four rows per lane
+    // The per-wave kernel keeps all NV rows of ceil((NK+1)/64) columns on every lane: for a large model that is
+    // minutes of compile time for a kernel whose stage vectors live in scratch.  Where the row-group form exists
+    // it is not instantiated beyond 4096 sensitivity entries, and opts.variant becomes a no-op for that model.
+    constexpr bool kPerWaveBuilt = !(kRowGroupOk && M::NV * (M::NK + 1) > 4096);
     const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
                          (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays);
     // row-group kernel: the row-lane kernel with the rows of a column split over several lanes,
     // when the emitter found a split that cuts the elements per lane (M::RG_OK)
     if constexpr (kRowGroupOk) {
-      if (a.opts.variant == SBM_VARIANT_ROW_GROUP || a.opts.variant == SBM_VARIANT_AUTO) {
+      if (a.opts.variant == SBM_VARIANT_ROW_GROUP || a.opts.variant == SBM_VARIANT_AUTO || !kPerWaveBuilt) {
         dim3 grid(a.n_traj, M::RG_NCH), block(64);
         if constexpr (M::RG_NCH > 1) {
           hipError_t e = hipSuccess;
@@ -1500,14 +1504,18 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
         return (int)hipGetLastError();
       }
     }
-    dim3 grid(a.n_traj), block(64);
-    if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+    if constexpr (kPerWaveBuilt) {
+      dim3 grid(a.n_traj), block(64);
+      if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+    }
   } else {
     // one trajectory per wave until the chip is full of lane-per-trajectory waves anyway
     constexpr bool kRowsOk = (M::NV <= 256);   // up to four state rows per lane
+    // one trajectory per LANE keeps NV stage-vector rows per lane: beyond 64 rows only the rows kernel is built
+    constexpr bool kLaneBuilt = !(kRowsOk && M::NV > 64);
     if constexpr (kRowsOk) {
-      if (a.n_traj < 65536 && a.opts.variant != SBM_VARIANT_PER_WAVE) {
+      if ((a.n_traj < 65536 && a.opts.variant != SBM_VARIANT_PER_WAVE) || !kLaneBuilt) {
         dim3 grid(a.n_traj), block(64);
         if (a.opts.method == SBM_DOPRI45)
           hipLaunchKernelGGL((sbm_state_rows_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
@@ -1516,9 +1524,11 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
         return (int)hipGetLastError();
       }
     }
-    dim3 grid((a.n_traj + 63) / 64), block(64);
-    if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_state_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((sbm_state_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+    if constexpr (kLaneBuilt) {
+      dim3 grid((a.n_traj + 63) / 64), block(64);
+      if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_state_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((sbm_state_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+    }
   }
   return (int)hipGetLastError();
 }

@@ -173,7 +173,7 @@ def _random_network(seed, n):
     return ModelSpec(name='rand%d_%d' % (n, seed), variables=[str(x) for x in xs], params=params, equations=eq)
 
 
-@pytest.mark.parametrize('seed,n', [(1, 6), (2, 11), (3, 17)])
+@pytest.mark.parametrize('seed,n', [(1, 6), (2, 11), (3, 17), (4, 30)])   # the last: 66 parameters, 3 column chunks
 def test_random_networks_all_variants(seed, n):
     """Emitter + kernels on networks nobody tuned them for: whatever classes, row splits and halo terms
     the generator comes up with, every variant must reproduce SciPy odeint on the generated callables."""

@@ -229,6 +229,36 @@ def test_rowgroup_form_of_an_irregular_network(tmp_path):
             assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize('seed,n', [(21, 45), (22, 70), (23, 130)])
+def test_rowgroup_chunks_of_large_irregular_networks_on_host(tmp_path, seed, n):
+    """Random rate-law networks beyond one column per lane (45 species, ~110 parameters) and beyond one state row
+    per lane (70 and 130 species): several classes, couplings at random distances (most terms are halo terms),
+    columns in chunks.  The lane-by-lane, chunk-by-chunk emulation of the row-group form equals the Python
+    emitter's sensitivity RHS and padding stays exactly zero."""
+    from tests.test_gpu_user_models import _random_network
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    gm = GeneratedModel(_random_network(seed, n))
+    k = gm.n_sens
+    assert gm.n_vars == n and k > 64 and 'RG_OK = true' in gm.hip_source and 'RG_NCH = 1;' not in gm.hip_source
+    hdr = tmp_path / 'net.hpp'
+    hdr.write_text(gm.hip_source)
+    so = str(tmp_path / 'h_net.so')
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-fPIC', '-shared', '-DSBM_MODEL_HEADER="%s"' % hdr,
+                           os.path.join(HERE, 'support', 'host_model_harness.cpp'), '-o', so])
+    lib = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rng = np.random.default_rng(seed)
+    for _ in range(2):
+        y = rng.uniform(0.05, 2.0, n + n * k)
+        p = rng.uniform(0.05, 2.0, len(gm.param_order))
+        ref = np.zeros(n + n * k)
+        gm.sens_model(y, 0.0, ref, p)
+        out = np.zeros(n + n * k)
+        assert lib.h_sens_rhs_rowgroup(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp),
+                                       p.ctypes.data_as(dp)) == 0
+        assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
+
+
 def test_rowgroup_plan():
     from sysbio_modeling_amd.symbolic.emit_rowgroup import plan
     assert plan(20, 40) == (3, 20, 2, 7, 1)    # cascade20: 14 elements on 60 lanes instead of 20 on 40
