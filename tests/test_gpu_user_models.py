@@ -109,6 +109,58 @@ def test_more_sensitivity_columns_than_lanes():
     assert np.array_equal(S_ic[0, 0], S0.ravel())
 
 
+def test_project_on_a_model_with_more_parameters_than_lanes():
+    """A Project on the 35-state / 70-parameter cascade (sensitivity columns in chunks): two experiments, a
+    'Shared' degradation rate, scale factors.  The project Jacobian equals central finite differences of the
+    batched residuals (the reference's own test style, tests/test_Project.py:145-176), column by column."""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    from sysbio_modeling_amd.model import OdeModel
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    n = 35
+    gm = GeneratedModel(models_zoo.cascade_spec(n, name='cascade35'))
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='cascade35')
+    p_nom = models_zoo.cascade_nominal_params(n)
+    times = np.linspace(5.0, 60.0, 8)
+    grid = np.linspace(0, 60.0, 1000)
+    rows = np.searchsorted(grid, times)
+    exps = []
+    for e, scale in enumerate((1.0, 1.6)):
+        p = p_nom.copy()
+        p[n] *= scale                                            # d0 differs between the experiments
+        Y = m.simulate(p, grid)[rows]
+        ms = [TimecourseMeasurement('x%d' % v, 2.0 * Y[:, v] * (1 + 0.03 * np.cos(np.arange(8) + v)), times.copy(),
+                                    0.05 * np.abs(Y[:, v]) + 0.01) for v in (7, 20, 34)]
+        exps.append(Experiment('exp_%d' % e, ms, experiment_settings={'cond': e}))
+    settings = {'Global': [k for k in gm.param_order if k != 'd0'], 'Shared': {'deg0': {'d0': ('cond',)}}}
+    proj = Project(m, exps, settings, {('x%d' % v): ('direct', v) for v in (7, 20, 34)},
+                   sf_groups=['x7', 'x20', 'x34'], reference_compat=False)
+    q = proj.n_project_params
+    assert q == 71
+    rng = np.random.default_rng(12)
+    theta = np.zeros(q)
+    names = list(gm.param_order)
+    for g, slots in proj.project_param_idx.items():
+        for key, gi in slots.items():
+            theta[gi] = np.log(p_nom[names.index('d0' if g == 'deg0' else g)])
+    theta += 0.05 * rng.standard_normal(q)
+    J = proj.calc_project_jacobian(theta)
+    assert J.shape == (48, q) and np.all(np.isfinite(J))
+    h = 1e-4
+    Th = np.repeat(theta[None, :], 2 * q, axis=0)
+    for k in range(q):
+        Th[2 * k, k] += h
+        Th[2 * k + 1, k] -= h
+    R = proj.residuals_batch(Th, rtol=1e-11, atol=1e-13)
+    J_fd = ((R[0::2] - R[1::2]) / (2 * h)).T
+    # columns of parameters with next to no influence are judged against the largest column (difference noise)
+    scale = np.abs(J).max(axis=0, keepdims=True) + 1e-2 * np.abs(J).max()
+    assert np.max(np.abs(J - J_fd) / scale) <= 1e-3
+    assert np.sum(np.abs(J).max(axis=0) > 1e-2 * np.abs(J).max()) >= 10      # not a test of zeros
+
+
 def test_more_state_variables_than_lanes():
     """70 species: a lane of the row kernels carries two state rows (lane, lane + 64).  18 of the 140 parameters
     have sensitivity columns (the rest are 'fixed': keeps the per-wave comparison kernel small).  Row-group
