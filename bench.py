@@ -366,6 +366,37 @@ def main():
             "algorithmic_GBps": n5 / (ms5 * 1e-3) * 2 * 8 * 2550 / 1e9,
             "failed_vectors": int((st5 != 0).sum().item())}
 
+        # A model beyond one row / one column per lane: 70 states, 140 parameters, 9870 coupled ODEs per trajectory
+        # (two state rows per lane, sensitivity columns in 12 chunks of 12, one wavefront each).  The plugin is
+        # built here (hipcc, ~15 s); a failure to build must not cost the headline line.
+        try:
+            from sysbio_modeling_amd.symbolic import GeneratedModel
+            gm7 = GeneratedModel(models_zoo.cascade_spec(70, name='cascade70'))
+            m7 = OdeModel(gm7.model, gm7.sens_model, gm7.n_vars, gm7.param_order, use_jit=False)
+            V7 = 1024
+            P7 = torch.from_numpy(models_zoo.cascade_ensemble(V7, n=70, spread=0.3)[1]).to(dev)
+            t7 = torch.tensor([50.0, 100.0], dtype=f64, device=dev)
+            Y7 = torch.empty((V7, 2, 70), dtype=f64, device=dev)
+            S7 = torch.empty((V7, 2, 70, 140), dtype=f64, device=dev)
+            st7 = torch.empty((V7,), dtype=i32, device=dev)
+            ns7 = torch.empty((V7,), dtype=i32, device=dev)
+            o7 = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+            m7.device_model.sens_dev(P7, t7, None, o7, Y7, S7, st7, ns7, None)
+            torch.cuda.synchronize(dev)
+            a7, b7 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a7.record()
+            m7.device_model.sens_dev(P7, t7, None, o7, Y7, S7, st7, ns7, None)
+            b7.record()
+            torch.cuda.synchronize(dev)
+            ms7 = a7.elapsed_time(b7)
+            n7 = int(ns7.sum().item())
+            extras["large_model_cascade70_dopri45"] = {
+                "ms": ms7, "steps": n7, "steps_per_s": n7 / (ms7 * 1e-3), "n_equations": 70 + 70 * 140, "vectors": V7,
+                "algorithmic_GBps": n7 / (ms7 * 1e-3) * 2 * 8 * (70 + 70 * 140) / 1e9,
+                "failed_vectors": int((st7 != 0).sum().item())}
+        except Exception as e:   # noqa: BLE001
+            extras["large_model_cascade70_dopri45"] = {"error": repr(e)[:200]}
+
     result = {
         "metric": "ensemble ODE-steps/sec (20-state model + fwd sens)",
         "value": value, "unit": "ODE-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
