@@ -13,8 +13,9 @@ with the reference's results is checked against ``odeint_oracle`` (LSODA) after 
       until max |delta_i| / (atol + rtol |ybar_i|) <= 1 (at most 12 iterations)
   S_{n+1} = 2 Sbar - S_n,  (I - h/2 J_y) Sbar = S_n + h/2 J_p, with J_y, J_p of the last evaluated iterate
   each output interval is cut into step_mult * ceil(dt / h0) equal steps.
-  graded=True (SBM_IMPLICIT_MIDPOINT_GRADED): the first step of the trajectory is cut into 13 midpoint
-  substeps of sizes hs * 2^-12, 2^-12, 2^-11, ..., 1/2 to resolve an initial layer.
+  graded=True (SBM_IMPLICIT_MIDPOINT_GRADED): the first BASE step of the trajectory (step_mult steps) is cut
+  into 13 groups of step_mult midpoint substeps of sizes hs * 2^-12, 2^-12, 2^-11, ..., 1/2 to resolve an
+  initial layer (grids nested across step_mult: what Richardson extrapolation needs).
 
 J_y and J_p are read off the generated sensitivity RHS (S' = J_y S + J_p): no second code path.
 Parity: "scheme-level" only -- pinned to LSODA through the convergence tests, not to reference vectors.
@@ -76,10 +77,14 @@ def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None
             t_start = t
             dy_prev = dy_prev * (hs / hs_prev if hs_prev > 0 else 0.0)
             hs_prev = hs
-            for s in range(ns):
-              # graded first step: substeps hs * 2^-12, 2^-12, 2^-11, ..., 1/2 (a fixed pattern relative to hs)
-              if graded and n_steps == 0:
-                  subs = [hs * 2.0 ** -GRADE] + [hs * 2.0 ** -(GRADE - j + 1) for j in range(1, GRADE + 1)]
+            s = -1
+            while s + 1 < ns:
+              s += 1
+              # graded first base step: step_mult substeps of each size hs * 2^-12, 2^-12, 2^-11, ..., 1/2
+              grade_now = graded and n_steps == 0
+              if grade_now:
+                  sizes = [hs * 2.0 ** -GRADE] + [hs * 2.0 ** -(GRADE - j + 1) for j in range(1, GRADE + 1)]
+                  subs = [w for w in sizes for _ in range(step_mult)]
               else:
                   subs = [hs]
               t_sub = t_start + s * hs
@@ -100,12 +105,15 @@ def integrate(gm, p, t_out, h0, rtol=1e-10, atol=1e-12, t0=0.0, y0=None, s0=None
                         break
                 if not conv:
                     raise RuntimeError("Newton did not converge")
-                dy_prev = 2.0 * (yb - y) * (2.0 if (len(subs) > 1 and sub > 0) else 1.0)
+                gj = sub // step_mult
+                dy_prev = 2.0 * (yb - y) * (2.0 if (len(subs) > 1 and gj > 0 and sub % step_mult == step_mult - 1) else 1.0)
                 y = 2.0 * yb - y
                 if with_sens:
                     Sb = np.linalg.solve(M, S + hh * Jp)
                     S = 2.0 * Sb - S
-              n_steps += 1
+              n_steps += step_mult if grade_now else 1
+              if grade_now:
+                  s += step_mult - 1
             t = target
         Y_out[io] = y
         S_out[io] = S.ravel()

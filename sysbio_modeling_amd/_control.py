@@ -7,8 +7,9 @@ stiff model "just works" there.  The device integrators are an explicit adaptive
 fixed-step implicit one (implicit midpoint, csrc/sbm_integrators.hpp).  Two loops close the gap:
 
 ``controlled_doubling``   The implicit midpoint rule with one Richardson level is run with n, 2n, 4n, ...
-    steps until two successive extrapolants agree: |E(2n) - E(n)| estimates the GLOBAL error of E(n), and
-    E(2n) -- returned -- is 4 to 16 times more accurate still.  Vectors leave the loop one by one as they
+    steps (every step halved exactly: ``step_mult``) until two successive extrapolants agree:
+    |E(2n) - E(n)| estimates the GLOBAL error of E(n), and E(2n) -- returned -- is 4 to 16 times more
+    accurate still.  Vectors leave the loop one by one as they
     converge; only the rest is integrated again.  Cost: 3n steps per level, a geometric series dominated
     by its last term.
 
@@ -82,13 +83,17 @@ def _assign(dst, idx, src, sel=None):
         dst[idx] = src
 
 
-def controlled_doubling(run, n_vectors, compare, rtol, atol, n0=256, max_doublings=7, accept=4.0):
+def controlled_doubling(run, n_vectors, compare, rtol, atol, max_doublings=9, accept=4.0, trace=None):
     """Global error control by step doubling.
 
-    run(idx, n_steps) -> (outputs, status, steps): ``outputs`` a dict name -> array with leading axis
-        len(idx) (the Richardson-extrapolated results of the vectors ``idx`` with n_steps base steps),
-        ``status`` / ``steps`` integer arrays of length len(idx).
+    run(idx, mult) -> (outputs, status, steps): ``outputs`` a dict name -> array with leading axis
+        len(idx) (the Richardson-extrapolated results of the vectors ``idx`` with EVERY step of the coarsest
+        run cut into ``mult`` = 1, 2, 4, ... equal parts -- the integrators' ``step_mult``; a step COUNT per
+        trajectory would not do: fixed-step runs take at least one step per output interval, so doubling a
+        count that is below the number of output times changes nothing), ``status`` / ``steps`` integer
+        arrays of length len(idx).
     compare : names of the outputs the error estimate is taken over.
+    trace : optional list; receives (level, vector indices, estimates in tolerance units) per level.
     accept : the estimate (in units of the tolerance) of the COARSER extrapolant below which the finer one
         is returned; 4 leaves the returned values within tolerance even where stiffness has reduced the
         extrapolant to second order.
@@ -103,20 +108,22 @@ def controlled_doubling(run, n_vectors, compare, rtol, atol, n0=256, max_doublin
     spent = np.zeros(n_vectors, dtype=np.int64)
     levels = np.zeros(n_vectors, dtype=np.int32)
     if n_vectors == 0:
-        out, _, _ = run(idx, int(n0))
+        out, _, _ = run(idx, 1)
         return out, status, spent, levels
-    prev, st_prev, steps = run(idx, int(n0))
+    prev, st_prev, steps = run(idx, 1)
     spent[idx] += _to_numpy(steps).astype(np.int64)
     result = {k: (v.clone() if _is_torch(v) else np.array(v, copy=True)) for k, v in prev.items()}
     status[idx] = _to_numpy(st_prev)
     for lv in range(1, max_doublings + 1):
-        cur, st_cur, steps = run(idx, int(n0) * 2 ** lv)
+        cur, st_cur, steps = run(idx, 2 ** lv)
         spent[idx] += _to_numpy(steps).astype(np.int64)
         st_cur = _to_numpy(st_cur).astype(np.int32)
         err = np.zeros(len(idx))
         for k in compare:
             err = np.maximum(err, _to_numpy(_err_per_vector(cur[k], prev[k], rtol, atol)))
         ok = (st_cur == SBM_OK) & (_to_numpy(st_prev) == SBM_OK) & (err <= accept)
+        if trace is not None:
+            trace.append((lv, idx.copy(), err.copy()))
         # everything still in the loop takes the finer result; the converged ones leave
         for k in result:
             _assign(result[k], idx, cur[k])

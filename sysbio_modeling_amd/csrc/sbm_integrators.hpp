@@ -1341,12 +1341,18 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
          // thinner than any affordable fixed step; no one-step method integrates through it accurately
          // without resolving it (a backward-Euler start-up damps the layer but misses its area: measured 60x
          // WORSE than doing nothing).  The geometric grading resolves layers down to hs / 4096 for 12 extra
-         // steps, and being a fixed pattern relative to hs it keeps the h^2 error expansion Richardson needs.
+         // steps.  Richardson needs NESTED grids to keep the h^2 expansion (an irregular first step graded relative
+         // to each run's own hs leaves an h^3 term: measured third-order convergence of the extrapolants): the
+         // pattern belongs to the first BASE step (step_mult = 1), and a run with step_mult = m cuts every one
+         // of its substeps into m equal parts -- m substeps of each size hs * 2^-k, covering the first m steps.
          constexpr int GRADE = 12;
-         const int nsub = (graded && n_acc == 0) ? GRADE + 1 : 1;     // wave-uniform
+         const int gm_ = a.opts.step_mult > 0 ? a.opts.step_mult : 1;
+         const bool grade_now = graded && n_acc == 0;                  // wave-uniform
+         const int nsub = grade_now ? (GRADE + 1) * gm_ : 1;
          double t_sub = fma((double)s, hs, t0);
          for (int sub = 0; sub < nsub && !failed; ++sub) {
-          const double hsub = nsub == 1 ? hs : ldexp(hs, -(sub == 0 ? GRADE : GRADE - sub + 1));
+          const int gj = sub / gm_;                                    // which size of the pattern
+          const double hsub = nsub == 1 ? hs : ldexp(hs, -(gj == 0 ? GRADE : GRADE - gj + 1));
           const double hh = 0.5 * hsub;
           const double tm = t_sub + hh;
           t_sub += hsub;
@@ -1405,7 +1411,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
           if (!failed && !conv) { status = SBM_NEWTON_FAIL; failed = true; }
           if (failed) break;
           // predictor for the next (sub)step: this increment, rescaled when the next substep is twice as long
-          dy_prev = 2.0 * (yb - y) * ((nsub > 1 && sub > 0) ? 2.0 : 1.0);
+          dy_prev = 2.0 * (yb - y) * ((nsub > 1 && gj > 0 && sub % gm_ == gm_ - 1) ? 2.0 : 1.0);
           y = fma(2.0, yb, -y);
           if (with_sens) {
             // J_y (the factors in m) and J_p (A) are those of the last evaluated iterate: within the
@@ -1420,7 +1426,11 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
             for (int i = 0; i < NV; ++i) z[i] = fma(2.0, b[i], -z[i]);
           }
          }
-          if (!failed) ++n_acc;
+          if (!failed) {
+            // the graded block covered the first gm_ steps of this interval
+            n_acc += grade_now ? gm_ : 1;
+            if (grade_now) s += gm_ - 1;
+          }
         }
         if (!failed) t = target;
       }

@@ -611,14 +611,14 @@ class Project(object):
         def controlled(idx):
             sub_th = th[torch.as_tensor(idx, device=th.device, dtype=torch.long)]
 
-            def run(sub, n):
+            def run(sub, mult):
                 t = sub_th[torch.as_tensor(sub, device=th.device, dtype=torch.long)]
-                return split(self._evaluate_once(t, jacobian, want, method='implicit_midpoint_graded', n_steps=n,
+                return split(self._evaluate_once(t, jacobian, want, method='implicit_midpoint_graded',
+                                                 n_steps=int(o.get('n_steps', 0) or 256), step_mult=mult,
                                                  extrapolate=1, rtol=max(1e-2 * rtol, 1e-13),
                                                  atol=max(1e-2 * atol, 1e-300), max_steps=0, **keep))
             return _control.controlled_doubling(run, len(idx), compare, rtol, atol,
-                                                n0=int(o.get('n_steps', 0) or 256),
-                                                max_doublings=int(o.get('max_doublings', 7)))
+                                                max_doublings=int(o.get('max_doublings', 9)))
         if method in _control.IMPLICIT_CONTROLLED:
             out, st, steps, _ = controlled(np.arange(V))
             stiff = np.ones(V, dtype=bool)

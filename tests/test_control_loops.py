@@ -8,8 +8,9 @@ import pytest
 from sysbio_modeling_amd import _control
 
 
-def _fake_run(exact, c, order=4, fail_below=None, calls=None):
-    def run(idx, n):
+def _fake_run(exact, c, order=4, fail_below=None, calls=None, n0=16):
+    def run(idx, mult):
+        n = n0 * mult
         if calls is not None:
             calls.append((len(idx), n))
         vals = exact[idx] + c[idx][:, None] / float(n) ** order
@@ -27,7 +28,7 @@ def test_vectors_leave_the_loop_as_they_converge():
     c = np.array([1e1, 1e4, 1e7])                       # easy, medium, hard
     calls = []
     out, st, spent, levels = _control.controlled_doubling(_fake_run(exact, c, calls=calls), 3, ['y'], 1e-9, 1e-12,
-                                                          n0=16, max_doublings=12)
+                                                          max_doublings=12)
     assert st.tolist() == [0, 0, 0]
     assert levels[0] < levels[1] < levels[2]
     # the returned values are the finer of the two compared runs: error well inside the tolerance
@@ -44,17 +45,17 @@ def test_failed_coarse_runs_do_not_stop_the_loop_and_unreachable_tolerances_are_
     exact = np.ones((2, 4))
     c = np.array([1e-3, 1e-3])
     fail_below = np.array([0, 128])                     # vector 1: Newton fails on the two coarsest grids
-    out, st, spent, levels = _control.controlled_doubling(_fake_run(exact, c, fail_below=fail_below), 2, ['y'],
-                                                          1e-9, 1e-12, n0=32, max_doublings=8)
+    out, st, spent, levels = _control.controlled_doubling(_fake_run(exact, c, fail_below=fail_below, n0=32), 2, ['y'],
+                                                          1e-9, 1e-12, max_doublings=8)
     assert st.tolist() == [0, 0] and levels.tolist() == [1, 3]    # 32|64 agree; 128|256 the first valid pair
     assert np.all(np.isfinite(out['y']))
     out, st, _, levels = _control.controlled_doubling(_fake_run(exact, np.array([1e12, 1e12])), 2, ['y'], 1e-12, 1e-15,
-                                                      n0=16, max_doublings=3)
+                                                      max_doublings=3)
     assert st.tolist() == [_control.SBM_TOL_NOT_REACHED] * 2 and levels.tolist() == [3, 3]
     assert np.allclose(out['y'], exact + 1e12 / (16 * 8) ** 4)        # the finest result is what comes back
     # a vector that still fails on the finest grid keeps that status
     out, st, _, _ = _control.controlled_doubling(_fake_run(exact, c, fail_below=np.array([0, 10 ** 9])), 2, ['y'],
-                                                 1e-9, 1e-12, n0=16, max_doublings=4)
+                                                 1e-9, 1e-12, max_doublings=4)
     assert st.tolist() == [0, 4]
 
 
@@ -88,6 +89,6 @@ def test_control_loops_on_torch_tensors():
     def run(idx, n):
         o, st, ns = base(idx, n)
         return {k: torch.from_numpy(v) for k, v in o.items()}, torch.from_numpy(st), torch.from_numpy(ns)
-    out, st, _, levels = _control.controlled_doubling(run, 2, ['y'], 1e-9, 1e-12, n0=16, max_doublings=10)
+    out, st, _, levels = _control.controlled_doubling(run, 2, ['y'], 1e-9, 1e-12, max_doublings=10)
     assert st.tolist() == [0, 0] and levels[0] < levels[1] and isinstance(out['y'], torch.Tensor)
     assert np.allclose(out['y'].numpy(), exact, rtol=1e-9)

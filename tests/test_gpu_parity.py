@@ -18,7 +18,7 @@ from tests.conftest import parity_err, PARITY_RTOL, PARITY_ATOL
 
 pytestmark = pytest.mark.gpu
 
-METHODS = [('dopri45', {}), ('rk4', {'n_steps': 65536})]
+METHODS = [('dopri45', {}), ('rk4', {'n_steps': 65536}), ('implicit_controlled', {}), ('auto', {})]
 
 
 def _from_zero(t_pts):
