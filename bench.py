@@ -284,7 +284,7 @@ def main():
                 "kernel_steps_per_s": k_steps / (k_ms * 1e-3),
                 "note": "algorithmic bytes (2*8*820 B per accepted step) / kernel time; the kernel keeps the "
                         "state in VGPRs, so real HBM traffic ('traffic', PMC) is far below this figure and the "
-                        "binding resource is VALU issue (profiles/r01d/pmc_summary.json)"}
+                        "binding resource is VALU issue (profiles/r01e/pmc_summary.json)"}
 
     extras = {}
     if not args.no_extras and rank == 0 and world == 1:   # single-GPU micro-benchmarks
