@@ -140,12 +140,15 @@ def controlled_doubling(run, n_vectors, compare, rtol, atol, max_doublings=9, ac
 
 def with_stiff_fallback(run_explicit, run_controlled, n_vectors):
     """run_explicit() -> (outputs, status, steps) for all vectors; run_controlled(idx) -> (outputs, status,
-    steps, levels) for the subset ``idx`` (numpy index array).  Returns (outputs, status, steps, stiff) with
+    steps, levels) for the subset ``idx`` (numpy index array), or None when the model has no implicit
+    integrator (more than 64 state variables).  Returns (outputs, status, steps, stiff) with
     ``stiff`` the boolean mask of the vectors that went through the implicit integrator."""
     out, st, steps = run_explicit()
     st = _to_numpy(st).astype(np.int32).copy()
     steps = _to_numpy(steps).astype(np.int64).copy()
     stiff = st != SBM_OK
+    if run_controlled is None:           # no implicit integrator for this model: the failures stand
+        return out, st, steps, np.zeros_like(stiff)
     if stiff.any():
         idx = np.flatnonzero(stiff)
         out2, st2, steps2, _ = run_controlled(idx)

@@ -212,7 +212,15 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
   return 0;
 }
 
+static int check_model_fits(const sbm_model* m, const sbm_integrator_opts& o, const char* who) {
+  if ((o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED) && m->info.n_vars > 64)
+    return sbm_fail(SBM_E_ARG, "%s: the implicit midpoint kernel holds one state variable per lane: n_vars <= 64 "
+                    "(model '%s' has %d)", who, m->info.name, m->info.n_vars);
+  return 0;
+}
+
 static int launch(sbm_model* m, int kind, const sbm_kernel_args& a, const char* who) {
+  if (int rc = check_model_fits(m, a.opts, who)) return rc;
   SBM_HIP(hipSetDevice(m->ctx->device));
   int e = m->launch(kind, &a, (void*)m->ctx->stream);
   if (e != 0) return sbm_fail(SBM_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString((hipError_t)e));
@@ -259,6 +267,7 @@ __global__ void __launch_bounds__(1024) k_order(const int32_t* __restrict__ step
 }
 
 static int launch_sens(sbm_model* m, sbm_kernel_args a, const char* who) {
+  if (int rc = check_model_fits(m, a.opts, who)) return rc;
   SBM_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->stream;
   const int T = a.n_traj;

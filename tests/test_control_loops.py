@@ -78,6 +78,9 @@ def test_stiff_fallback_touches_only_failed_vectors():
     out, st2, _, stiff = _control.with_stiff_fallback(lambda: (explicit, np.zeros(V, dtype=np.int32), np.full(V, 7)),
                                                      lambda idx: pytest.fail("not expected"), V)
     assert not stiff.any()
+    # a model without an implicit integrator: the failures stand
+    out, st2, _, stiff = _control.with_stiff_fallback(lambda: (explicit, st, np.full(V, 7)), None, V)
+    assert st2.tolist() == st.tolist() and not stiff.any()
 
 
 def test_control_loops_on_torch_tensors():

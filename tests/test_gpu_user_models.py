@@ -192,6 +192,11 @@ def test_more_state_variables_than_lanes():
     y0 = np.concatenate([0.2 + 0.01 * np.arange(n), rng.standard_normal(n * 18)])
     S_ic, Y_ic = m.calc_jacobian_batch(P[:1], np.array([0.0, 1.0]), init_conditions=y0, return_states=True)
     assert np.array_equal(Y_ic[0, 0], y0[:n]) and np.array_equal(S_ic[0, 0], y0[n:])
+    # the implicit kernel holds one state variable per lane: a clear error, and 'auto' runs without its fallback
+    with pytest.raises(Exception, match='n_vars <= 64'):
+        m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=64)
+    assert np.array_equal(m.calc_jacobian_batch(P, t[idx], method='auto'), res['auto'][0])
+    assert not m.last_info['stiff'].any()
 
 
 def _random_network(seed, n):
