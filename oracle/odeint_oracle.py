@@ -11,6 +11,8 @@ reference's exact call
     odeint(func_wrapper, init_conditions, t_sim, Dfun=None, col_deriv=True,
            rtol=1e-10, atol=1e-10)                      (ode_model.py:122-123,167-168)
 
+(or Dfun = the analytic Jacobian callback, the reference's ``use_jac`` path, :114-120,154-160)
+
 on a right-hand side with the reference callback contract f(y, t, yout, p).
 
 PINNED: tests/test_oracle_golden.py checks this module against
@@ -60,9 +62,22 @@ def _wrap_c(cfn, n_out, params):
     return func_wrapper
 
 
+def _wrap_jac(jac, n, params):
+    """jac_wrapper of the reference (ode_model.py:114-120,154-160): one zero matrix allocated per call of
+    simulate / calc_jacobian, filled in place (the generated code writes its non-zero entries only)."""
+    jacout = np.zeros((n, n))
+    p = np.ascontiguousarray(params, dtype=np.float64)
+
+    def jac_wrapper(y, t):
+        jac(y, t, jacout, p)
+        return jacout
+    return jac_wrapper
+
+
 def simulate(model, experiment_params, t_sim, init_conditions=None, n_vars=None, full_output=False,
-             use_c=False):
-    """ode_model.py:128-169.  ``model``: callable f(y,t,yout,p) or a GeneratedModel."""
+             use_c=False, model_jac=None):
+    """ode_model.py:128-169.  ``model``: callable f(y,t,yout,p) or a GeneratedModel.  ``model_jac``: the
+    reference's optional analytic Jacobian callback (``use_jac`` path, :154-160), handed to LSODA as Dfun."""
     gm = None if callable(model) else model
     if gm is not None:
         n_vars = gm.n_vars
@@ -72,13 +87,15 @@ def simulate(model, experiment_params, t_sim, init_conditions=None, n_vars=None,
         fw = _wrap_c(gm.c_library().sbm_rhs, len(init_conditions), experiment_params)
     else:
         fw = _wrap(gm.model if gm is not None else model, len(init_conditions), experiment_params)
-    return odeint(fw, init_conditions, t_sim, Dfun=None, col_deriv=True, rtol=RTOL, atol=ATOL,
+    dfun = _wrap_jac(model_jac, len(init_conditions), experiment_params) if model_jac is not None else None
+    return odeint(fw, init_conditions, t_sim, Dfun=dfun, col_deriv=True, rtol=RTOL, atol=ATOL,
                   full_output=full_output)
 
 
 def calc_jacobian(sens_model, experiment_params, t_sim, init_conditions=None, n_vars=None, n_sens=None,
-                  full_output=False, use_c=False, return_states=False):
-    """ode_model.py:83-126: integrate [y; S], return the S part ``sim[:, n_vars:]``."""
+                  full_output=False, use_c=False, return_states=False, sens_model_jac=None):
+    """ode_model.py:83-126: integrate [y; S], return the S part ``sim[:, n_vars:]``.  ``sens_model_jac``:
+    optional analytic Jacobian of the augmented system (``use_jac`` path, :114-120)."""
     gm = None if callable(sens_model) else sens_model
     if gm is not None:
         n_vars, n_sens = gm.n_vars, gm.n_sens
@@ -88,7 +105,8 @@ def calc_jacobian(sens_model, experiment_params, t_sim, init_conditions=None, n_
         fw = _wrap_c(gm.c_library().sbm_sens_rhs, len(init_conditions), experiment_params)
     else:
         fw = _wrap(gm.sens_model if gm is not None else sens_model, len(init_conditions), experiment_params)
-    out = odeint(fw, init_conditions, t_sim, Dfun=None, col_deriv=True, rtol=RTOL, atol=ATOL,
+    dfun = _wrap_jac(sens_model_jac, len(init_conditions), experiment_params) if sens_model_jac is not None else None
+    out = odeint(fw, init_conditions, t_sim, Dfun=dfun, col_deriv=True, rtol=RTOL, atol=ATOL,
                  full_output=full_output)
     sim, info = (out if full_output else (out, None))
     sens = sim[:, n_vars:]                                          # :125

@@ -54,6 +54,26 @@ class GeneratedModel(object):
         self._plugin = None
         self._c_lib = None
 
+    # -- analytic ODE Jacobians (the reference's model_jac / sens_model_jac, Dfun of LSODA) -----------------
+    def _jacobian_callables(self):
+        if getattr(self, '_jac_fns', None) is None:
+            from .emit import emit_python_jacobians
+            self.jacobian_python_source = emit_python_jacobians(self.spec, self.derived)
+            ns = {}
+            exec(compile(self.jacobian_python_source, '<generated %s jacobians>' % self.spec.name, 'exec'), ns)
+            self._jac_fns = (ns['model_jac'], ns['sens_model_jac'])
+        return self._jac_fns
+
+    @property
+    def model_jac(self):
+        """``model_jac(y, t, jacout, p)``: jacout[b, a] = d f_a / d y_b, (n, n) (generated on first use)."""
+        return self._jacobian_callables()[0]
+
+    @property
+    def sens_model_jac(self):
+        """Jacobian of the augmented system, (n + n*k) square, same contract (generated on first use)."""
+        return self._jacobian_callables()[1]
+
     # -- GPU plugin ---------------------------------------------------------
     def header_path(self):
         from .. import build

@@ -272,6 +272,90 @@ def emit_python(spec: ModelSpec, derived: Derived = None) -> str:
     return "\n".join(L)
 
 
+def emit_python_jacobians(spec: ModelSpec, derived: Derived = None) -> str:
+    """Python source of ``model_jac`` and ``sens_model_jac``: the analytic ODE Jacobians the reference's
+    ``make_ode_model_jacobian`` prints (symbolic/sympy_tools.py:219-269) and its ``OdeModel`` hands to LSODA as
+    ``Dfun`` with ``col_deriv=True`` (model/ode_model.py:114-120,154-160).
+
+    Contract: ``jac(y, t, jacout, p) -> None`` writes the NON-ZERO entries of ``jacout[b, a] = d f_a / d y_b``
+    (derivatives down the columns) into a caller-allocated zero matrix, (n, n) for ``model_jac`` and (N, N),
+    N = n + n*k, for ``sens_model_jac`` -- as the reference's generated code does (zero entries are comments
+    there, :238-241).  With S' = J_y S + J_p the augmented Jacobian has three blocks:
+
+        d f_i / d y_m                      = J_y[i, m]
+        d S'[i, j] / d S[l, j]             = J_y[i, l]                               (same column j only)
+        d S'[i, j] / d y_m                 = sum_l dJ_y[i, l]/dy_m * S[l, j] + dJ_p[i, j]/dy_m
+
+    The second derivatives are taken on the sparse J_y / J_p entries, not on n*k expanded equations.
+    """
+    d = derived or Derived(spec)
+    n, k = spec.n_vars, spec.n_sens
+    pr = _ExprPrinter(_symbol_map(spec), rcp="(1.0/(%s))", lang='py')
+    pad = "    "
+    ysyms = [Symbol(v) for v in spec.variables]
+    # second derivatives: (i, l, m) -> d J_y[i,l] / d y_m ;  (i, j, m) -> d J_p[i,j] / d y_m
+    hy, hp = [], []
+    for e_idx, (i, l, expr) in enumerate(d.jy):
+        for m, ym in enumerate(ysyms):
+            if ym in expr.free_symbols:
+                dd = sympy.diff(expr, ym)
+                if dd != 0:
+                    hy.append((i, l, m, _canon_rcp(_cheapest(dd))))
+    for e_idx, (i, j, expr) in enumerate(d.jp):
+        for m, ym in enumerate(ysyms):
+            if ym in expr.free_symbols:
+                dd = sympy.diff(expr, ym)
+                if dd != 0:
+                    hp.append((i, j, m, _canon_rcp(_cheapest(dd))))
+    exprs = list(d.jy_c) + [h[3] for h in hy] + [h[3] for h in hp]
+    repl, red = cse(exprs, symbols=sympy.numbered_symbols('x_'), optimizations='basic')
+    jy_red = red[:len(d.jy)]
+    hy_red = red[len(d.jy):len(d.jy) + len(hy)]
+    hp_red = red[len(d.jy) + len(hy):]
+    L = ["from math import exp, log, sqrt, pow, sin, cos, tanh", "", "",
+         "def model_jac(y, t, jacout, p):"]
+    repl_y, red_y = cse(list(d.jy_c), symbols=sympy.numbered_symbols('x_'), optimizations='basic')
+    for s_, e in repl_y:
+        L.append(pad + "%s = %s" % (s_, pr.doprint(e)))
+    for (i, m, _), e in zip(d.jy, red_y):
+        L.append(pad + "jacout[%d, %d] = (%s)" % (m, i, pr.doprint(e)))
+    if not d.jy:
+        L.append(pad + "pass")
+    L += ["", "", "def sens_model_jac(y, t, jacout, p):"]
+    for s_, e in repl:
+        L.append(pad + "%s = %s" % (s_, pr.doprint(e)))
+    for e_idx, ((i, l, _), e) in enumerate(zip(d.jy, jy_red)):
+        L.append(pad + "jy_%d = %s" % (e_idx, pr.doprint(e)))
+        L.append(pad + "jacout[%d, %d] = jy_%d" % (l, i, e_idx))
+        if k:
+            L.append(pad + "for j in range(%d):" % k)
+            L.append(pad * 2 + "jacout[%d + j, %d + j] = jy_%d" % (n + l * k, n + i * k, e_idx))
+    # lower-left block, grouped by (equation row i, state m)
+    by_im = OrderedDict()
+    for (i, l, m, _), e in zip(hy, hy_red):
+        by_im.setdefault((i, m), dict(hy=[], hp=[]))['hy'].append((l, e))
+    for (i, j, m, _), e in zip(hp, hp_red):
+        by_im.setdefault((i, m), dict(hy=[], hp=[]))['hp'].append((j, e))
+    for q, ((i, m), terms) in enumerate(by_im.items()):
+        names = []
+        for t_idx, (l, e) in enumerate(terms['hy']):
+            L.append(pad + "h_%d_%d = %s" % (q, t_idx, pr.doprint(e)))
+            names.append(("h_%d_%d" % (q, t_idx), l))
+        if names and k:
+            L.append(pad + "for j in range(%d):" % k)
+            L.append(pad * 2 + "jacout[%d, %d + j] = %s" % (
+                m, n + i * k, " + ".join("%s*y[%d + j]" % (nm, n + l * k) for nm, l in names)))
+        elif k and terms['hp']:
+            L.append(pad + "for j in range(%d):" % k)
+            L.append(pad * 2 + "jacout[%d, %d + j] = 0.0" % (m, n + i * k))
+        for j, e in terms['hp']:
+            L.append(pad + "jacout[%d, %d] += (%s)" % (m, n + i * k + j, pr.doprint(e)))
+    if not d.jy and not by_im:
+        L.append(pad + "pass")
+    L.append("")
+    return "\n".join(L)
+
+
 # ----------------------------------------------------------------------------
 # C (oracle RHS / CPU baseline RHS; plays the role numba plays for the reference)
 # ----------------------------------------------------------------------------
