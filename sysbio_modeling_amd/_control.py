@@ -6,16 +6,16 @@ Adams and BDF formulas by itself and controls its local error (model/ode_model.p
 stiff model "just works" there.  The device integrators are an explicit adaptive pair (DOPRI45) and a
 fixed-step implicit one (implicit midpoint, csrc/sbm_integrators.hpp).  Two loops close the gap:
 
-``controlled_doubling``   The implicit midpoint rule with one Richardson level is run with n, 2n, 4n, ...
-    steps (every step halved exactly: ``step_mult``) until two successive extrapolants agree:
-    |E(2n) - E(n)| estimates the GLOBAL error of E(n), and E(2n) -- returned -- is 4 to 16 times more
-    accurate still.  Vectors leave the loop one by one as they
-    converge; only the rest is integrated again.  Cost: 3n steps per level, a geometric series dominated
-    by its last term.
+``controlled_romberg``   The implicit midpoint rule is run with n, 2n, 4n, ... steps (every step halved
+    exactly: ``step_mult``) and the runs are combined in a Romberg table (the symmetric rule's global error
+    expands in h^2) until the once-extrapolated results of two successive rows agree: a third of their
+    difference bounds the GLOBAL error of the finer one even where stiffness has reduced the order to two.
+    Vectors leave the loop one by one as they converge; only the rest is integrated again.  Every run is
+    used once: the cost is a geometric series dominated by its last term.
 
 ``with_stiff_fallback``   DOPRI45 with a step budget first; the vectors that exhaust it (the step size of
     an explicit method on a stiff problem is bounded by stability, not accuracy) or fail otherwise are
-    integrated again with ``controlled_doubling``.  The switch is per parameter vector, as LSODA's is per
+    integrated again with ``controlled_romberg``.  The switch is per parameter vector, as LSODA's is per
     trajectory.
 
 Both work on numpy arrays or torch tensors (whatever ``run`` returns).
@@ -83,59 +83,98 @@ def _assign(dst, idx, src, sel=None):
         dst[idx] = src
 
 
-def controlled_doubling(run, n_vectors, compare, rtol, atol, max_doublings=9, accept=4.0, trace=None):
-    """Global error control by step doubling.
+def _where_rows(mask, a, b):
+    """rows of a where mask else rows of b (mask: numpy bool over the leading axis)."""
+    if _is_torch(a):
+        import torch
+        m = torch.as_tensor(mask, device=a.device).reshape((-1,) + (1,) * (a.dim() - 1))
+        return torch.where(m, a, b)
+    return np.where(mask.reshape((-1,) + (1,) * (a.ndim - 1)), a, b)
 
-    run(idx, mult) -> (outputs, status, steps): ``outputs`` a dict name -> array with leading axis
-        len(idx) (the Richardson-extrapolated results of the vectors ``idx`` with EVERY step of the coarsest
-        run cut into ``mult`` = 1, 2, 4, ... equal parts -- the integrators' ``step_mult``; a step COUNT per
-        trajectory would not do: fixed-step runs take at least one step per output interval, so doubling a
-        count that is below the number of output times changes nothing), ``status`` / ``steps`` integer
-        arrays of length len(idx).
-    compare : names of the outputs the error estimate is taken over.
+
+def controlled_romberg(run, n_vectors, compare, rtol, atol, max_doublings=9, accept=1.0, trace=None):
+    """Global error control with a Romberg table: every run is used once.
+
+    run(idx, mult) -> (outputs, status, steps): the RAW (second-order, unextrapolated) results of the vectors
+        ``idx`` with every base step cut into ``mult`` parts (a step COUNT per trajectory would not do in place
+        of ``mult``: fixed-step runs take at least one step per output interval, so doubling a count below the
+        number of output times changes nothing).
+    Row k of the table: T[k][0] = run(mult = 2^k), T[k][1] = (4 T[k][0] - T[k-1][0]) / 3 (fourth order: the
+    symmetric rule's error expands in h^2), T[k][2] = (16 T[k][1] - T[k-1][1]) / 15 (sixth order where the
+    expansion holds).
+
+    Estimate and acceptance.  |T[k][1] - T[k-1][1]| / 3 bounds the error of T[k][1] as long as the error
+    falls by at least 4 per halving -- true in the asymptotic regime (16) and on stiff systems, where order
+    reduction leaves second order (measured on stiff50: 95 and 260 per halving on the way in).  The sharper
+    textbook estimates |T[k][j] - T[k][j-1]| of the higher columns are NOT used: those entries differ by
+    (row difference) / (4^j - 1) by construction, so they agree with each other whether or not they are right,
+    and on stiff50 the columns beyond the first are 10 - 20 times WORSE than the first until the very end
+    (scripts/dev_romberg_table.py).  Returned: T[k][2], which at acceptance differs from T[k][1] by at most a
+    fifth of the tolerance and is orders of magnitude better on smooth problems.  A failed run (NaN rows) only
+    invalidates the entries built on it: the table recovers two levels later.
+
     trace : optional list; receives (level, vector indices, estimates in tolerance units) per level.
-    accept : the estimate (in units of the tolerance) of the COARSER extrapolant below which the finer one
-        is returned; 4 leaves the returned values within tolerance even where stiffness has reduced the
-        extrapolant to second order.
 
-    Returns (outputs for all vectors, status (V,), steps spent (V,), levels used (V,)).  A vector whose
-    estimate never met the tolerance carries its finest result and status SBM_TOL_NOT_REACHED; one whose
-    finest run failed carries that run's status.
+    Returns (outputs for all vectors, status (V,), steps spent (V,), levels used (V,)).  A vector whose estimate
+    never met the tolerance carries its finest result and status SBM_TOL_NOT_REACHED; one whose finest run
+    failed carries that run's status and raw output.
     """
     idx = np.arange(n_vectors)
-    result = None
     status = np.zeros(n_vectors, dtype=np.int32)
     spent = np.zeros(n_vectors, dtype=np.int64)
     levels = np.zeros(n_vectors, dtype=np.int32)
+    first, st0, steps = run(idx, 1)
     if n_vectors == 0:
-        out, _, _ = run(idx, 1)
-        return out, status, spent, levels
-    prev, st_prev, steps = run(idx, 1)
+        return first, status, spent, levels
     spent[idx] += _to_numpy(steps).astype(np.int64)
-    result = {k: (v.clone() if _is_torch(v) else np.array(v, copy=True)) for k, v in prev.items()}
-    status[idx] = _to_numpy(st_prev)
+    status[idx] = _to_numpy(st0)
+    result = {k: (v.clone() if _is_torch(v) else np.array(v, copy=True)) for k, v in first.items()}
+    keys = list(first.keys())
+    prev_row = {k: [first[k]] for k in keys}           # T[k-1][0..]
     for lv in range(1, max_doublings + 1):
         cur, st_cur, steps = run(idx, 2 ** lv)
         spent[idx] += _to_numpy(steps).astype(np.int64)
         st_cur = _to_numpy(st_cur).astype(np.int32)
-        err = np.zeros(len(idx))
-        for k in compare:
-            err = np.maximum(err, _to_numpy(_err_per_vector(cur[k], prev[k], rtol, atol)))
-        ok = (st_cur == SBM_OK) & (_to_numpy(st_prev) == SBM_OK) & (err <= accept)
+        row = {k: [cur[k], (4.0 * cur[k] - prev_row[k][0]) / 3.0] for k in keys}
+        est = np.full(len(idx), np.inf)
+        if lv >= 2:
+            est = np.zeros(len(idx))
+            for k in compare:
+                est = np.maximum(est, _to_numpy(_err_per_vector(row[k][1], prev_row[k][1], rtol, atol)) / 3.0)
+            for k in keys:
+                row[k].append((16.0 * row[k][1] - prev_row[k][1]) / 15.0)
+        pick = {k: row[k][-1] for k in keys}
+        # a table entry built on a failed run is NaN: fall back to the best finite entry of the row
+        for k in keys:
+            for j in range(len(row[k]) - 2, -1, -1):
+                bad = ~_to_numpy(_finite_rows(pick[k]))
+                if not bad.any():
+                    break
+                pick[k] = _where_rows(bad, row[k][j], pick[k])
+        ok = (st_cur == SBM_OK) & (est <= accept)
         if trace is not None:
-            trace.append((lv, idx.copy(), err.copy()))
-        # everything still in the loop takes the finer result; the converged ones leave
-        for k in result:
-            _assign(result[k], idx, cur[k])
+            trace.append((lv, idx.copy(), est.copy()))
+        failed = st_cur != SBM_OK
+        for k in keys:
+            if failed.any():         # a failed run comes back as the kernel left it (NaN / inf rows), not as NaN algebra
+                pick[k] = _where_rows(failed, cur[k], pick[k])
+            _assign(result[k], idx, pick[k])
         levels[idx] = lv
-        status[idx] = np.where(ok, SBM_OK, np.where(st_cur != SBM_OK, st_cur, SBM_TOL_NOT_REACHED))
+        status[idx] = np.where(ok, SBM_OK, np.where(failed, st_cur, SBM_TOL_NOT_REACHED))
         if ok.all():
             break
         keep = np.flatnonzero(~ok)
         idx = idx[keep]
-        prev = {k: _index(v, keep) for k, v in cur.items()}
-        st_prev = st_cur[keep]
+        prev_row = {k: [_index(t, keep) for t in row[k]] for k in keys}
     return result, status, spent, levels
+
+
+def _finite_rows(x):
+    """per leading index: are all entries finite?"""
+    if _is_torch(x):
+        import torch
+        return torch.isfinite(x.reshape(x.shape[0], -1)).all(dim=1)
+    return np.isfinite(x.reshape(x.shape[0], -1)).all(axis=1)
 
 
 def with_stiff_fallback(run_explicit, run_controlled, n_vectors):

@@ -615,10 +615,12 @@ class Project(object):
                 t = sub_th[torch.as_tensor(sub, device=th.device, dtype=torch.long)]
                 return split(self._evaluate_once(t, jacobian, want, method='implicit_midpoint_graded',
                                                  n_steps=int(o.get('n_steps', 0) or 256), step_mult=mult,
-                                                 extrapolate=1, rtol=max(1e-2 * rtol, 1e-13),
+                                                 extrapolate=0, rtol=max(1e-2 * rtol, 1e-13),
                                                  atol=max(1e-2 * atol, 1e-300), max_steps=0, **keep))
-            return _control.controlled_doubling(run, len(idx), compare, rtol, atol,
-                                                max_doublings=int(o.get('max_doublings', 9)))
+            # Romberg on the ASSEMBLED outputs: residuals, scale factors, Jacobian ... are smooth functions of the
+            # discrete solution, so they inherit its expansion in h^2
+            return _control.controlled_romberg(run, len(idx), compare, rtol, atol,
+                                               max_doublings=int(o.get('max_doublings', 9)))
         if method in _control.IMPLICIT_CONTROLLED:
             out, st, steps, _ = controlled(np.arange(V))
             stiff = np.ones(V, dtype=bool)

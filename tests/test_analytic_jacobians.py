@@ -76,7 +76,7 @@ def test_oracle_use_jac_path_equals_the_reference(name):
 
 def test_a_transposed_jacobian_changes_the_stiff_result():
     """The index convention matters: handing LSODA the transpose (col_deriv=False layout) makes its BDF Newton
-    iteration work with a wrong matrix -- it still converges here, more slowly, along another step sequence."""
+    iteration work with a wrong matrix: more work along another step sequence, or LSODA giving up."""
     gm = _model('stiff12')
     g = np.load(os.path.join(HERE, 'golden', 'jac_path_ref.npz'))
     p, grid, idx = g['stiff12_P'][0], g['stiff12_t'], g['stiff12_idx']
@@ -88,5 +88,8 @@ def test_a_transposed_jacobian_changes_the_stiff_result():
     (Y_ok, info_ok) = oo.simulate(gm, p, grid, model_jac=gm.model_jac, full_output=True)
     (Y_t, info_t) = oo.simulate(gm, p, grid, model_jac=transposed, full_output=True)
     assert np.allclose(Y_ok[idx], g['stiff12_Y_jac'][0], rtol=1e-12, atol=1e-14)
+    assert info_ok['message'] == 'Integration successful.'
     assert not np.array_equal(Y_ok, Y_t)
-    assert info_t['nfe'][-1] > info_ok['nfe'][-1]
+    # ... or gives up ("Excess work done on this call (perhaps wrong Dfun type)")
+    gave_up = info_t['message'] != 'Integration successful.'
+    assert gave_up or info_t['nfe'][-1] > info_ok['nfe'][-1]

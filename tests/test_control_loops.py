@@ -1,62 +1,70 @@
 """Host-side control loops (sysbio_modeling_amd/_control.py) on synthetic integrators: no GPU involved.
 
-``run`` stands in for the device call: an "extrapolated result" with a known error constant per vector,
-E(n) = exact + c_v / n^4, optionally failing below some n (a Newton failure on too coarse a grid)."""
+``run`` stands in for the device call: a "raw" result of a symmetric scheme with known error constants per
+vector, y(n) = exact + c2/n^2 + c4/n^4 + c6/n^6, optionally failing below some n (a Newton failure on too
+coarse a grid)."""
 import numpy as np
 import pytest
 
 from sysbio_modeling_amd import _control
 
 
-def _fake_run(exact, c, order=4, fail_below=None, calls=None, n0=16):
+def _raw_run(exact, c2, c4, c6, fail_below=None, calls=None, n0=16):
     def run(idx, mult):
-        n = n0 * mult
+        n = float(n0 * mult)
         if calls is not None:
-            calls.append((len(idx), n))
-        vals = exact[idx] + c[idx][:, None] / float(n) ** order
+            calls.append((len(idx), int(n)))
+        vals = exact[idx] + (c2[idx] / n ** 2 + c4[idx] / n ** 4 + c6[idx] / n ** 6)[:, None]
         st = np.zeros(len(idx), dtype=np.int32)
         if fail_below is not None:
             bad = n < fail_below[idx]
             st[bad] = 4
             vals[bad] = np.nan
-        return {'y': vals, 'aux': vals * 2.0}, st, np.full(len(idx), 3 * n, dtype=np.int32)
+        return {'y': vals, 'aux': -vals}, st, np.full(len(idx), int(n), dtype=np.int32)
     return run
 
 
-def test_vectors_leave_the_loop_as_they_converge():
-    exact = np.array([[1.0, 2.0, 0.0], [3.0, -1.0, 0.5], [0.2, 0.1, 0.3]])
-    c = np.array([1e1, 1e4, 1e7])                       # easy, medium, hard
-    calls = []
-    out, st, spent, levels = _control.controlled_doubling(_fake_run(exact, c, calls=calls), 3, ['y'], 1e-9, 1e-12,
-                                                          max_doublings=12)
-    assert st.tolist() == [0, 0, 0]
-    assert levels[0] < levels[1] < levels[2]
-    # the returned values are the finer of the two compared runs: error well inside the tolerance
-    assert np.all(np.abs(out['y'] - exact) <= 1e-9 * np.maximum(np.abs(exact), 1e-3 * np.abs(exact).max(axis=1, keepdims=True)) + 1e-12)
-    assert np.allclose(out['aux'], 2.0 * out['y'])      # every output follows, not only the compared one
-    # fewer vectors per call as the loop goes on, steps doubling
+def test_romberg_table_uses_every_run_once_and_vectors_leave_as_they_converge():
+    exact = np.array([[1.0, 2.0], [3.0, -1.0], [0.5, 0.25]])
+    c2, c4, c6 = np.array([1.0, 30.0, 1e3]), np.array([5.0, 1e3, 1e5]), np.array([10.0, 1e4, 1e7])   # easy ... hard
+    calls, trace = [], []
+    out, st, spent, levels = _control.controlled_romberg(_raw_run(exact, c2, c4, c6, calls=calls), 3, ['y'], 1e-9, 1e-12,
+                                                         max_doublings=12, trace=trace)
+    assert st.tolist() == [0, 0, 0] and levels[0] < levels[1] < levels[2]
+    assert np.all(np.abs(out['y'] - exact) <= 1e-9 * np.abs(exact) + 1e-12)
+    assert np.allclose(out['aux'], -out['y'], rtol=1e-15)              # every output follows, not only the compared one
+    # one run per level, steps doubling, fewer vectors per call as the loop goes on
+    assert [n for _, n in calls] == [16 * 2 ** k for k in range(len(calls))]
     sizes = [n_vec for n_vec, _ in calls]
     assert sizes[0] == 3 and sizes[-1] == 1 and sizes == sorted(sizes, reverse=True)
-    assert [n for _, n in calls] == [16 * 2 ** k for k in range(len(calls))]
-    assert spent[2] == sum(3 * n for _, n in calls) and spent[0] < spent[1] < spent[2]
+    assert spent[2] == sum(n for _, n in calls) and spent[0] < spent[1] < spent[2]
+    # the estimate is that of the once-extrapolated column: it falls by about 16 per level ...
+    hard = [e[list(i).index(2)] for lv, i, e in trace if 2 in i and lv >= 4]
+    assert len(hard) >= 2 and 10.0 < hard[-2] / hard[-1] < 24.0
+    # ... while the returned entry is the sixth-order one: far inside the tolerance
+    assert np.all(np.abs(out['y'] - exact) <= 1e-11 * np.abs(exact) + 1e-13)
+    # a loose tolerance stops as soon as there are two extrapolated rows to compare
+    _, st, _, levels = _control.controlled_romberg(_raw_run(exact, c2, c4, c6), 3, ['y'], 1.0, 1.0, max_doublings=12)
+    assert st.tolist() == [0, 0, 0] and levels.tolist() == [2, 2, 2]
 
 
-def test_failed_coarse_runs_do_not_stop_the_loop_and_unreachable_tolerances_are_flagged():
-    exact = np.ones((2, 4))
-    c = np.array([1e-3, 1e-3])
-    fail_below = np.array([0, 128])                     # vector 1: Newton fails on the two coarsest grids
-    out, st, spent, levels = _control.controlled_doubling(_fake_run(exact, c, fail_below=fail_below, n0=32), 2, ['y'],
-                                                          1e-9, 1e-12, max_doublings=8)
-    assert st.tolist() == [0, 0] and levels.tolist() == [1, 3]    # 32|64 agree; 128|256 the first valid pair
-    assert np.all(np.isfinite(out['y']))
-    out, st, _, levels = _control.controlled_doubling(_fake_run(exact, np.array([1e12, 1e12])), 2, ['y'], 1e-12, 1e-15,
-                                                      max_doublings=3)
+def test_romberg_table_recovers_after_failed_coarse_runs_and_flags_unreachable_tolerances():
+    exact = np.ones((2, 3))
+    one = np.array([1.0, 1.0])
+    fail_below = np.array([0, 100])                    # vector 1: the runs with 16, 32, 64 steps fail
+    out, st, _, levels = _control.controlled_romberg(_raw_run(exact, one, one, one, fail_below=fail_below), 2, ['y'],
+                                                     1e-5, 1e-8, max_doublings=10)
+    # vector 0 stops at 16 | 32 | 64; vector 1 needs 128 | 256 | 512: the first two valid extrapolants
+    assert st.tolist() == [0, 0] and levels.tolist() == [2, 5]
+    assert np.all(np.abs(out['y'] - exact) <= 1e-5)
+    out, st, _, levels = _control.controlled_romberg(_raw_run(exact, 1e9 * one, one, one), 2, ['y'], 1e-13, 1e-16,
+                                                     max_doublings=3)
     assert st.tolist() == [_control.SBM_TOL_NOT_REACHED] * 2 and levels.tolist() == [3, 3]
-    assert np.allclose(out['y'], exact + 1e12 / (16 * 8) ** 4)        # the finest result is what comes back
-    # a vector that still fails on the finest grid keeps that status
-    out, st, _, _ = _control.controlled_doubling(_fake_run(exact, c, fail_below=np.array([0, 10 ** 9])), 2, ['y'],
-                                                 1e-9, 1e-12, max_doublings=4)
-    assert st.tolist() == [0, 4]
+    assert np.all(np.isfinite(out['y']))               # the finest result is what comes back
+    # a vector that still fails on the finest grid keeps that status and the kernel's own (NaN) rows
+    out, st, _, _ = _control.controlled_romberg(_raw_run(exact, one, one, one, fail_below=np.array([0, 10 ** 9])), 2,
+                                                ['y'], 1e-5, 1e-8, max_doublings=4)
+    assert st.tolist() == [0, 4] and np.all(np.isnan(out['y'][1])) and np.all(np.isfinite(out['y'][0]))
 
 
 def test_stiff_fallback_touches_only_failed_vectors():
@@ -86,12 +94,12 @@ def test_stiff_fallback_touches_only_failed_vectors():
 def test_control_loops_on_torch_tensors():
     torch = pytest.importorskip('torch')
     exact = np.array([[1.0, 2.0], [3.0, 4.0]])
-    c = np.array([1e3, 1e7])
-    base = _fake_run(exact, c)
+    base = _raw_run(exact, np.array([1.0, 1e3]), np.array([1.0, 1e5]), np.array([1.0, 1e7]),
+                    fail_below=np.array([0, 40]))
 
-    def run(idx, n):
-        o, st, ns = base(idx, n)
+    def run(idx, mult):
+        o, st, ns = base(idx, mult)
         return {k: torch.from_numpy(v) for k, v in o.items()}, torch.from_numpy(st), torch.from_numpy(ns)
-    out, st, _, levels = _control.controlled_doubling(run, 2, ['y'], 1e-9, 1e-12, max_doublings=10)
+    out, st, _, levels = _control.controlled_romberg(run, 2, ['y'], 1e-9, 1e-12, max_doublings=10)
     assert st.tolist() == [0, 0] and levels[0] < levels[1] and isinstance(out['y'], torch.Tensor)
     assert np.allclose(out['y'].numpy(), exact, rtol=1e-9)
