@@ -199,6 +199,48 @@ def test_more_state_variables_than_lanes():
     assert not m.last_info['stiff'].any()
 
 
+def test_three_state_rows_per_lane_against_finite_differences():
+    """A random network of 130 species and ~300 parameters (39 000 sensitivity ODEs per trajectory: three state
+    rows per lane, columns in chunks).  LSODA on the augmented system is out of reach here, so the columns are
+    checked another way: d y / d p_j by central differences of the STATE-ONLY kernel (a different kernel, no
+    sensitivity code involved), and the states against LSODA on the 130 state equations."""
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    from sysbio_modeling_amd.model import OdeModel
+    from oracle import odeint_oracle as oo
+    gm = GeneratedModel(_random_network(23, 130))
+    n, k = gm.n_vars, gm.n_sens
+    assert n == 130 and k > 256 and 'RG_OK = true' in gm.hip_source
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=gm.spec.name)
+    rng = np.random.default_rng(5)
+    p = np.exp(rng.uniform(np.log(0.3), np.log(1.5), len(gm.param_order)))
+    t = np.linspace(0, 10.0, 1000)
+    idx = np.array([0, 400, 999])
+    S, Y = m.calc_jacobian_batch(p[None, :], t[idx], return_states=True)
+    assert m.last_info['status'].tolist() == [0]
+    Yr = oo.simulate(gm, p, t)[idx]
+    assert parity_err(Y[0], Yr) <= 1.0
+    S = S[0].reshape(len(idx), n, k)
+    cols = rng.choice(k, size=12, replace=False)
+    names = list(gm.param_order)
+    P2 = np.repeat(p[None, :], 2 * len(cols), axis=0)
+    hs = []
+    for q, j in enumerate(cols):
+        pj = names.index(gm.sens_params[j])
+        h = 1e-4 * p[pj]
+        P2[2 * q, pj] += h
+        P2[2 * q + 1, pj] -= h
+        hs.append(h)
+    Yp = m.simulate_batch(P2, t[idx], rtol=1e-12, atol=1e-14)
+    assert m.last_info['status'].max() == 0
+    for q, j in enumerate(cols):
+        fd = (Yp[2 * q] - Yp[2 * q + 1]) / (2 * hs[q])
+        scale = np.abs(fd).max() + 1e-12
+        assert np.max(np.abs(S[:, :, j] - fd)) <= 1e-5 * scale, (j, gm.sens_params[j])
+    # the fixed-step integrator on the same right-hand side lands on the same numbers
+    S_rk = m.calc_jacobian_batch(p[None, :], t[idx], method='rk4', n_steps=4096)[0].reshape(len(idx), n, k)
+    assert np.allclose(S_rk, S, rtol=1e-6, atol=1e-8 * np.abs(S).max())
+
+
 def _random_network(seed, n):
     """Random rate-law network: every species is produced from one or two others (mass action or
     saturating), degraded linearly, some with product inhibition; bounded by construction."""
