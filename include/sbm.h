@@ -43,12 +43,15 @@ enum {
    * the model generator worked out for the model's Jacobian pattern; the sensitivities are
    * the exact derivative of the scheme (one linear solve per column with the matrix Newton
    * just factored).  Second order, symmetric: the error expands in h^2, so two runs with
-   * step_mult 1 and 2 extrapolate to fourth order.  Needs n_vars <= 64 and n_sens <= 64.     */
+   * step_mult 1 and 2 extrapolate to fourth order.  Needs n_vars <= 64 (any n_sens: one
+   * wavefront per 64 sensitivity columns).                                                   */
   SBM_IMPLICIT_MIDPOINT = 2,
   /* The same with a graded first step, cut into 13 midpoint substeps of sizes
    * h0 * 2^-12, 2^-12, 2^-11, ..., 1/2: for initial conditions off a fast manifold -- the
    * reference always starts from y = 0 (model/ode_model.py:151-152) -- whose initial layer no
-   * fixed step resolves.                                                                     */
+   * fixed step resolves.  The pattern belongs to the first step of the step_mult = 1 grid;
+   * with step_mult = m every substep is cut into m parts, so that the grids of runs with
+   * different step_mult are nested (what the h^2 expansion needs).                           */
   SBM_IMPLICIT_MIDPOINT_GRADED = 3
 };
 
@@ -73,11 +76,18 @@ typedef struct sbm_integrator_opts {
  * they are evaluated once, lane i working on row i (rows of the same kinetic form
  * side by side), and handed to the columns through LDS.  ROW_GROUP: ROW_LANE with
  * the rows of a column split over several lanes, so that all 64 lanes carry
- * equations and the Runge-Kutta stages fit the register file.  ROW_LANE / ROW_GROUP
- * need n_vars <= 64 and n_sens <= 64; AUTO picks ROW_GROUP when the model generator
- * found a paying split, else ROW_LANE when the model fits, else PER_WAVE.  A forced
- * variant the model does not support falls back in the same order.  For the state-only
- * entry points PER_WAVE selects the one-trajectory-per-lane kernel. */
+ * equations and the Runge-Kutta stages fit the register file; sensitivity columns
+ * that do not fit one wavefront are cut into chunks, one wavefront each (the columns
+ * of a trajectory are coupled only through the state, of which every chunk integrates
+ * a copy under its own step-size control: status and step counts of a trajectory are
+ * the worst / largest over its chunks), and a lane carries up to four state rows.
+ * ROW_LANE needs n_vars <= 64 and n_sens <= 64, ROW_GROUP n_vars <= 256 (any n_sens);
+ * AUTO picks ROW_GROUP when the model generator found a paying split, else ROW_LANE
+ * when the model fits, else PER_WAVE.  A forced variant the model does not support
+ * falls back in the same order; for large models that have the ROW_GROUP form (more
+ * than 4096 sensitivity entries) the other kernels are not built and the field is
+ * ignored.  For the state-only entry points PER_WAVE selects the one-trajectory-per-lane
+ * kernel (models up to 64 state variables). */
 enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2, SBM_VARIANT_ROW_GROUP = 3 };
 
 /* per-trajectory status written next to the results (the reference does not
@@ -89,8 +99,8 @@ enum {
   SBM_NON_FINITE = 2,
   SBM_STEP_UNDERFLOW = 3,
   SBM_NEWTON_FAIL = 4,  /* implicit midpoint: Newton did not converge in 12 iterations */
-  SBM_TOL_NOT_REACHED = 5  /* set by the HOST control loop around the implicit integrator (step doubling until two
-                              extrapolants agree, sysbio_modeling_amd/_control.py), never by a kernel */
+  SBM_TOL_NOT_REACHED = 5  /* set by the HOST control loop around the implicit integrator (Romberg table over runs
+                              with step_mult = 1, 2, 4, ..., sysbio_modeling_amd/_control.py), never by a kernel */
 };
 
 /* ---- context ----------------------------------------------------------- */
