@@ -113,6 +113,13 @@ def controlled_romberg(run, n_vectors, compare, rtol, atol, max_doublings=9, acc
     fifth of the tolerance and is orders of magnitude better on smooth problems.  A failed run (NaN rows) only
     invalidates the entries built on it: the table recovers two levels later.
 
+    Fast path for smooth solutions.  The higher columns may be trusted once the table itself shows the
+    asymptotic regime: the row-to-row differences of the fourth-order column fell by 16 (within [12, 20]) at
+    this level AND the one before, and those of the sixth-order column by 64 (within [40, 100]).  Then
+    |T[k][3] - T[k][2]| -- the estimate of the sixth-order entry -- decides, against a quarter of the tolerance,
+    and the eighth-order entry T[k][3] is returned: two to three levels (4 - 8 times fewer steps) earlier on
+    cascade20.  stiff50 never passes the ratio test (its ratios: 177, 99, 5.3, 11.7, 94, 258).
+
     trace : optional list; receives (level, vector indices, estimates in tolerance units) per level.
 
     Returns (outputs for all vectors, status (V,), steps spent (V,), levels used (V,)).  A vector whose estimate
@@ -131,19 +138,40 @@ def controlled_romberg(run, n_vectors, compare, rtol, atol, max_doublings=9, acc
     result = {k: (v.clone() if _is_torch(v) else np.array(v, copy=True)) for k, v in first.items()}
     keys = list(first.keys())
     prev_row = {k: [first[k]] for k in keys}           # T[k-1][0..]
+    d1_prev = np.full(n_vectors, np.nan)               # row differences of columns 1 and 2 at the previous level
+    d2_prev = np.full(n_vectors, np.nan)
+    r1_prev = np.zeros(n_vectors, dtype=bool)          # column-1 ratio test passed at the previous level
     for lv in range(1, max_doublings + 1):
         cur, st_cur, steps = run(idx, 2 ** lv)
         spent[idx] += _to_numpy(steps).astype(np.int64)
         st_cur = _to_numpy(st_cur).astype(np.int32)
         row = {k: [cur[k], (4.0 * cur[k] - prev_row[k][0]) / 3.0] for k in keys}
         est = np.full(len(idx), np.inf)
+        d1 = np.full(len(idx), np.nan)
+        d2 = np.full(len(idx), np.nan)
+        smooth = np.zeros(len(idx), dtype=bool)
         if lv >= 2:
-            est = np.zeros(len(idx))
+            d1 = np.zeros(len(idx))
             for k in compare:
-                est = np.maximum(est, _to_numpy(_err_per_vector(row[k][1], prev_row[k][1], rtol, atol)) / 3.0)
+                d1 = np.maximum(d1, _to_numpy(_err_per_vector(row[k][1], prev_row[k][1], rtol, atol)))
+            est = d1 / 3.0
             for k in keys:
                 row[k].append((16.0 * row[k][1] - prev_row[k][1]) / 15.0)
-        pick = {k: row[k][-1] for k in keys}
+        if lv >= 3:
+            d2 = np.zeros(len(idx))
+            for k in compare:
+                d2 = np.maximum(d2, _to_numpy(_err_per_vector(row[k][2], prev_row[k][2], rtol, atol)))
+            for k in keys:
+                row[k].append((64.0 * row[k][2] - prev_row[k][2]) / 63.0)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            r1 = (d1_prev / d1 >= 12.0) & (d1_prev / d1 <= 20.0)
+            r2 = (d2_prev / d2 >= 40.0) & (d2_prev / d2 <= 100.0)
+        if lv >= 4:
+            smooth = r1 & r1_prev & r2 & (d2 / 63.0 <= 0.25 * accept)
+            est = np.where(smooth, d2 / 63.0 / 0.25, est)      # in units of ``accept``, like the other branch
+        # conservative branch returns the sixth-order entry, the fast path the eighth-order one
+        pick = {k: (_where_rows(smooth, row[k][3], row[k][2]) if lv >= 4 and smooth.any() else
+                    row[k][min(lv, 2)]) for k in keys}
         # a table entry built on a failed run is NaN: fall back to the best finite entry of the row
         for k in keys:
             for j in range(len(row[k]) - 2, -1, -1):
@@ -166,6 +194,7 @@ def controlled_romberg(run, n_vectors, compare, rtol, atol, max_doublings=9, acc
         keep = np.flatnonzero(~ok)
         idx = idx[keep]
         prev_row = {k: [_index(t, keep) for t in row[k]] for k in keys}
+        d1_prev, d2_prev, r1_prev = d1[keep], d2[keep], r1[keep]
     return result, status, spent, levels
 
 

@@ -38,10 +38,11 @@ def test_romberg_table_uses_every_run_once_and_vectors_leave_as_they_converge():
     sizes = [n_vec for n_vec, _ in calls]
     assert sizes[0] == 3 and sizes[-1] == 1 and sizes == sorted(sizes, reverse=True)
     assert spent[2] == sum(n for _, n in calls) and spent[0] < spent[1] < spent[2]
-    # the estimate is that of the once-extrapolated column: it falls by about 16 per level ...
-    hard = [e[list(i).index(2)] for lv, i, e in trace if 2 in i and lv >= 4]
-    assert len(hard) >= 2 and 10.0 < hard[-2] / hard[-1] < 24.0
-    # ... while the returned entry is the sixth-order one: far inside the tolerance
+    # the conservative estimate is that of the once-extrapolated column: it falls by about 16 per level, until
+    # the table has shown the asymptotic regime and the higher columns take over (the last entry)
+    hard = [e[list(i).index(2)] for lv, i, e in trace if 2 in i and lv >= 3]
+    assert len(hard) >= 3 and 10.0 < hard[-3] / hard[-2] < 24.0 and hard[-2] / hard[-1] > 100.0
+    # ... and the returned entry is a high-order one: far inside the tolerance
     assert np.all(np.abs(out['y'] - exact) <= 1e-11 * np.abs(exact) + 1e-13)
     # a loose tolerance stops as soon as there are two extrapolated rows to compare
     _, st, _, levels = _control.controlled_romberg(_raw_run(exact, c2, c4, c6), 3, ['y'], 1.0, 1.0, max_doublings=12)
@@ -65,6 +66,29 @@ def test_romberg_table_recovers_after_failed_coarse_runs_and_flags_unreachable_t
     out, st, _, _ = _control.controlled_romberg(_raw_run(exact, one, one, one, fail_below=np.array([0, 10 ** 9])), 2,
                                                 ['y'], 1e-5, 1e-8, max_doublings=4)
     assert st.tolist() == [0, 4] and np.all(np.isnan(out['y'][1])) and np.all(np.isfinite(out['y'][0]))
+
+
+def test_fast_path_needs_the_asymptotic_regime_to_show_in_the_table():
+    """Vector 0: a clean expansion in h^2 (smooth solution) -- the ratio tests pass and the eighth-order entry is
+    accepted levels before the conservative rule would stop.  Vector 1: the same size of error, but with an h^3 term
+    (what order reduction or an irregular grid leaves): the ratios are off, the conservative rule decides, and
+    the result is within the tolerance all the same."""
+    exact = np.array([[1.0, -2.0], [1.0, -2.0]])
+    n0 = 16
+
+    def run(idx, mult):
+        n = float(n0 * mult)
+        err = np.stack([1e2 / n ** 2 + 1e4 / n ** 4 + 1e6 / n ** 6 + 1e8 / n ** 8,
+                        1e2 / n ** 2 + 3e3 / n ** 3 + 1e4 / n ** 4])[idx]
+        return {'y': exact[idx] + err[:, None]}, np.zeros(len(idx), dtype=np.int32), np.full(len(idx), int(n))
+    trace = []
+    out, st, spent, levels = _control.controlled_romberg(run, 2, ['y'], 1e-10, 1e-13, max_doublings=14, trace=trace)
+    assert st.tolist() == [0, 0]
+    assert np.all(np.abs(out['y'] - exact) <= 1e-10 * np.abs(exact) + 1e-13)
+    assert levels[0] + 2 <= levels[1] and spent[0] * 4 <= spent[1]
+    # the conservative rule alone on vector 0: where would it have stopped?  (estimates of vector 1 fall by 8)
+    e1 = [e[list(i).index(1)] for lv, i, e in trace if 1 in i and lv >= 3]
+    assert 6.0 < e1[-2] / e1[-1] < 10.0
 
 
 def test_stiff_fallback_touches_only_failed_vectors():
