@@ -87,7 +87,9 @@ typedef struct sbm_integrator_opts {
  * falls back in the same order; for large models that have the ROW_GROUP form (more
  * than 4096 sensitivity entries) the other kernels are not built and the field is
  * ignored.  For the state-only entry points PER_WAVE selects the one-trajectory-per-lane
- * kernel (models up to 64 state variables). */
+ * kernel (models up to 64 state variables), AUTO the one-trajectory-per-wavefront kernel
+ * up to 2047 trajectories and its packed form (two or four trajectories per wavefront,
+ * bit-identical results) beyond, ROW_LANE / ROW_GROUP always the unpacked one. */
 enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2, SBM_VARIANT_ROW_GROUP = 3 };
 
 /* per-trajectory status written next to the results (the reference does not

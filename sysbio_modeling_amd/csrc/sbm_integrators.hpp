@@ -910,6 +910,133 @@ __global__ void __launch_bounds__(64) sbm_state_rows_kernel(sbm_kernel_args a) {
 }
 
 // ===========================================================================
+// Packed state-rows kernel: several trajectories per wavefront.
+//
+// A model with few state variables leaves most lanes of the state-rows kernel idle (cascade20: 20 of 64), and
+// with thousands of trajectories the kernel is bound by instruction issue, not latency: every wavefront costs
+// the same issue slots whether 20 or 60 of its lanes carry equations.  Here a wavefront is cut into 64 / SEG
+// segments of SEG = 16 or 32 lanes, one trajectory each (lane i of a segment = state component i).  The
+// segments share the instruction stream but not the control flow: each trajectory has its own time, step size
+// and accept / reject decisions (per-lane values, uniform within a segment), so the wavefront runs until its
+// slowest segment is done and a rejected step of one segment idles the others for one evaluation -- a few per
+// cent.  Reductions stay inside a segment: DPP within rows of 16, one ds_bpermute across the two rows of a
+// 32-lane segment.  LDS exchange of the stage state is per segment (operand indices offset by the segment base).
+// Used from 2048 trajectories on (below that the chip is not full and the unpacked kernel has the lower latency).
+// ===========================================================================
+// Sum over the lanes of a segment, the SAME BITS in every lane: the result steers the step size, and lanes of one
+// trajectory that disagree in the last bit drift apart in time (measured: 3e-4 relative error with a rotation-based
+// reduction whose lanes add the same numbers in different orders).  Every level is an exchange between two lanes that
+// both form own + other -- commutative, hence identical: quad_perm (xor 1, xor 2), row_half_mirror (i <-> 7 - i),
+// row_mirror (i <-> 15 - i) on DPP, the two rows of a 32-lane segment through ds_bpermute.
+template <int SEG>
+__device__ __forceinline__ float sbm_seg_sumf(float v) {
+  v += sbm_dpp<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
+  v += sbm_dpp<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
+  v += sbm_dpp<0x141, 0xf>(v);   // row_half_mirror
+  v += sbm_dpp<0x140, 0xf>(v);   // row_mirror: every lane of the row of 16 holds the row's sum
+  if constexpr (SEG == 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+template <int SEG>
+__device__ __forceinline__ double sbm_seg_sum(double v) {
+#pragma unroll
+  for (int off = SEG / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);   // stays inside the aligned segment
+  return v;
+}
+
+template <class M, int SEG>
+struct PackedStateRowSystem {
+  static constexpr int NV = 0;           // no column rows: the lane's state component is the "extra" element
+  static constexpr int NVX = 1;
+  static constexpr int CPL = 1;
+  static constexpr int NCS = 1;
+  static constexpr bool kUniform = false;
+  __device__ __forceinline__ static constexpr int col_of(int, int) { return 0; }
+  double* Y;                     // [64] in LDS: stage state, segment by segment
+  int lane, cls;
+  bool has_row;
+  int yidx[M::RL_MAXYS];
+  double ps[M::RL_MAXPS];
+
+  struct Pending { double ys[M::RL_MAXYS]; };
+  struct Token { double f; };
+  __device__ __forceinline__ Pending issue(double, const double (&z)[1][1]) const {
+    Pending p;
+    Y[lane] = z[0][0];
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[s] = Y[yidx[s]];
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    return p;
+  }
+  __device__ __forceinline__ Token eval(const Pending& p, double t) const {
+    Token k;
+    double jy[M::RL_MAXJY], jp[M::RL_MAXJP];   // dead: the compiler drops the Jacobian arithmetic
+    k.f = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
+    M::class_dispatch(cls, t, p.ys, ps, k.f, jy, jp);
+    k.f = cls >= 0 ? k.f : 0.0;
+    return k;
+  }
+  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][1]) const { dz[0][0] = k.f; }
+  __device__ __forceinline__ void finish(const Token&, double, const double (&)[1][1], double (&)[1][1]) const {}
+  __device__ __forceinline__ void rhs(double t, const double (&z)[1][1], double (&dz)[1][1]) const {
+    extra_out(eval(issue(t, z), t), dz);
+  }
+  __device__ __forceinline__ float norm(const float (&)[1], float xsum) const {
+    const float x = has_row ? sbm_nan_to_inf(xsum) : 0.f;
+    return sqrtf(sbm_seg_sumf<SEG>(x) * (1.0f / M::NV));
+  }
+  __device__ __forceinline__ double sum(double v) const { return sbm_seg_sum<SEG>(v); }
+};
+
+template <class M, int METHOD, int SEG>
+__global__ void __launch_bounds__(64) sbm_state_packed_kernel(sbm_kernel_args a) {
+  using Sys = PackedStateRowSystem<M, SEG>;
+  static_assert((SEG == 16 || SEG == 32) && M::NV <= SEG, "one state component per lane of a segment");
+  constexpr int TPW = 64 / SEG;          // trajectories per wavefront
+  __shared__ double Ysh[64];
+  const int lane = threadIdx.x;
+  const int seg = lane / SEG, li = lane % SEG;
+  const int traj_raw = (int)blockIdx.x * TPW + seg;
+  const bool live = traj_raw < a.n_traj;         // segments beyond the batch integrate a copy of the last trajectory
+  const int traj = live ? traj_raw : a.n_traj - 1;
+  Ysh[lane] = 0.0;
+  Sys sys;
+  sys.Y = Ysh;
+  sys.lane = lane;
+  sys.has_row = li < M::NV;
+  const int row = sys.has_row ? li : 0;
+  sys.cls = sys.has_row ? M::rl_class(row) : -1;
+  const double* P = a.P + (size_t)traj * M::NP;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[s] = M::rl_ys(s, row) + seg * SEG;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[s] = P[M::rl_ps(s, row)];
+  __syncthreads();
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+  double z[1][1];
+  z[0][0] = (a.y0 && sys.has_row) ? a.y0[li] : 0.0;
+  double* Yt = a.Y + (size_t)traj * a.n_t * M::NV;
+  auto store = [&](int io, const double (&zz)[1][1]) {
+    if (sys.has_row && live) Yt[(size_t)io * M::NV + li] = zz[0][0];
+  };
+  SbmTrajOut r;
+  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
+  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+  if (li == 0 && live) {
+    if (a.status) a.status[traj] = r.status;
+    if (a.n_steps) a.n_steps[traj] = r.n_acc;
+    if (a.n_reject) a.n_reject[traj] = r.n_rej;
+  }
+}
+
+// ===========================================================================
 // Row-group sensitivity kernel: the row-lane kernel with the rows of a column split over G lanes.
 //
 // One trajectory per wavefront, as before; the state still lives one component per lane and the
@@ -1524,6 +1651,18 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     constexpr bool kRowsOk = (M::NV <= 256);   // up to four state rows per lane
     // one trajectory per LANE keeps NV stage-vector rows per lane: beyond 64 rows only the rows kernel is built
     constexpr bool kLaneBuilt = !(kRowsOk && M::NV > 64);
+    // several trajectories per wavefront once the chip is full: models of up to 32 state variables
+    if constexpr (M::NV <= 32 && M::NV >= 2) {
+      if (a.n_traj >= 2048 && a.n_traj < 65536 && a.opts.variant == SBM_VARIANT_AUTO) {
+        constexpr int SEG = M::NV <= 16 ? 16 : 32;
+        dim3 grid((a.n_traj + 64 / SEG - 1) / (64 / SEG)), block(64);
+        if (a.opts.method == SBM_DOPRI45)
+          hipLaunchKernelGGL((sbm_state_packed_kernel<M, SBM_DOPRI45, SEG>), grid, block, 0, stream, a);
+        else
+          hipLaunchKernelGGL((sbm_state_packed_kernel<M, SBM_RK4_FIXED, SEG>), grid, block, 0, stream, a);
+        return (int)hipGetLastError();
+      }
+    }
     if constexpr (kRowsOk) {
       if ((a.n_traj < 65536 && a.opts.variant != SBM_VARIANT_PER_WAVE) || !kLaneBuilt) {
         dim3 grid(a.n_traj), block(64);

@@ -293,6 +293,34 @@ def test_full_ensemble_properties(gpu_models):
         assert float(torch.max(torch.abs(fd - s) / (scale + 1e-12))) < 1e-5
 
 
+@pytest.mark.parametrize('name,n_traj', [('cascade20', 4096), ('cascade20', 2049), ('michaelis_menten', 3003)])
+def test_packed_state_kernel_equals_the_unpacked_one(gpu_models, zoo, name, n_traj):
+    """From 2048 trajectories on the state-only path packs several trajectories into one wavefront (two segments of
+    32 lanes for the 20-state model, four of 16 for the 2-state one), each with its own time, step size and
+    accept / reject decisions.  The segment reductions return the same bits in every lane, so the numbers are
+    those of the one-trajectory-per-wavefront kernel (selected with a kernel variant) bit for bit -- also for a
+    trajectory count that leaves the last wavefront partly empty, ragged step counts, and the fixed-step method."""
+    from sysbio_modeling_amd import models_zoo
+    m = gpu_models(name)
+    rng = np.random.default_rng(17)
+    if name == 'cascade20':
+        _, P = models_zoo.cascade_ensemble(n_traj)
+        t = _from_zero(models_zoo.CASCADE_MEASURE_TIMES)
+    else:
+        P = np.array([1e-3, 1e-3, 0.01, 0.01, 1e-3]) * np.exp(0.8 * rng.standard_normal((n_traj, 5)))
+        t = np.linspace(0, 100, 7)
+    for method, kw in (('dopri45', {}), ('rk4', {'n_steps': 512})):
+        Ya = m.simulate_batch(P, t, method=method, **kw)
+        na, sa = m.last_info['n_steps'].copy(), m.last_info['status'].copy()
+        Yb = m.simulate_batch(P, t, method=method, variant='row_lane', **kw)
+        assert sa.max() == 0 and np.array_equal(na, m.last_info['n_steps'])
+        assert np.array_equal(Ya, Yb)
+    assert na.min() == na.max() or method == 'dopri45'
+    # a batch below the threshold takes the unpacked kernel either way: same numbers for the same vectors
+    Ys = m.simulate_batch(P[:100], t)
+    assert np.array_equal(Ys, m.simulate_batch(P, t)[:100])
+
+
 # ---------------------------------------------------------------------------
 # Project
 # ---------------------------------------------------------------------------
