@@ -920,7 +920,7 @@ __global__ void __launch_bounds__(64) sbm_state_rows_kernel(sbm_kernel_args a) {
 // and accept / reject decisions (per-lane values, uniform within a segment), so the wavefront runs until its
 // slowest segment is done and a rejected step of one segment idles the others for one evaluation -- a few per
 // cent.  Reductions stay inside a segment: DPP within rows of 16, one ds_bpermute across the two rows of a
-// 32-lane segment.  LDS exchange of the stage state is per segment (operand indices offset by the segment base).
+// 32-lane segment (the fixed-step method reduces nothing and packs segments of any multiple of four lanes).  LDS exchange of the stage state is per segment (operand indices offset by the segment base).
 // Used from 2048 trajectories on (below that the chip is not full and the unpacked kernel has the lower latency).
 // ===========================================================================
 // Sum over the lanes of a segment, the SAME BITS in every lane: the result steers the step size, and lanes of one
@@ -952,6 +952,7 @@ struct PackedStateRowSystem {
   static constexpr int NCS = 1;
   static constexpr bool kUniform = false;
   __device__ __forceinline__ static constexpr int col_of(int, int) { return 0; }
+  static constexpr bool kDpp = (SEG == 16 || SEG == 32);   // the widths the segment reductions exist for
   double* Y;                     // [64] in LDS: stage state, segment by segment
   int lane, cls;
   bool has_row;
@@ -986,24 +987,30 @@ struct PackedStateRowSystem {
   __device__ __forceinline__ void rhs(double t, const double (&z)[1][1], double (&dz)[1][1]) const {
     extra_out(eval(issue(t, z), t), dz);
   }
+  // (only the adaptive driver reduces: fixed-step runs may use any segment width)
   __device__ __forceinline__ float norm(const float (&)[1], float xsum) const {
+    static_assert(kDpp, "segment reductions: widths 16 and 32");
     const float x = has_row ? sbm_nan_to_inf(xsum) : 0.f;
     return sqrtf(sbm_seg_sumf<SEG>(x) * (1.0f / M::NV));
   }
-  __device__ __forceinline__ double sum(double v) const { return sbm_seg_sum<SEG>(v); }
+  __device__ __forceinline__ double sum(double v) const {
+    static_assert(kDpp, "segment reductions: widths 16 and 32");
+    return sbm_seg_sum<SEG>(v);
+  }
 };
 
 template <class M, int METHOD, int SEG>
 __global__ void __launch_bounds__(64) sbm_state_packed_kernel(sbm_kernel_args a) {
   using Sys = PackedStateRowSystem<M, SEG>;
-  static_assert((SEG == 16 || SEG == 32) && M::NV <= SEG, "one state component per lane of a segment");
-  constexpr int TPW = 64 / SEG;          // trajectories per wavefront
+  static_assert(SEG >= 4 && SEG <= 32 && SEG % 4 == 0 && M::NV <= SEG, "one state component per lane of a segment");
+  constexpr int TPW = 64 / SEG;          // trajectories per wavefront (lanes beyond TPW * SEG idle along with the last one)
   __shared__ double Ysh[64];
   const int lane = threadIdx.x;
-  const int seg = lane / SEG, li = lane % SEG;
+  const int seg = lane / SEG < TPW ? lane / SEG : TPW - 1;
+  const int li = lane - seg * SEG;               // >= SEG on the idle tail lanes
   const int traj_raw = (int)blockIdx.x * TPW + seg;
-  const bool live = traj_raw < a.n_traj;         // segments beyond the batch integrate a copy of the last trajectory
-  const int traj = live ? traj_raw : a.n_traj - 1;
+  const bool live = traj_raw < a.n_traj && li < SEG;   // segments beyond the batch integrate a copy of the last trajectory
+  const int traj = traj_raw < a.n_traj ? traj_raw : a.n_traj - 1;
   Ysh[lane] = 0.0;
   Sys sys;
   sys.Y = Ysh;
@@ -1027,7 +1034,7 @@ __global__ void __launch_bounds__(64) sbm_state_packed_kernel(sbm_kernel_args a)
     if (sys.has_row && live) Yt[(size_t)io * M::NV + li] = zz[0][0];
   };
   SbmTrajOut r;
-  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
+  if constexpr (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
   else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
   if (li == 0 && live) {
     if (a.status) a.status[traj] = r.status;
@@ -1654,12 +1661,19 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     // several trajectories per wavefront once the chip is full: models of up to 32 state variables
     if constexpr (M::NV <= 32 && M::NV >= 2) {
       if (a.n_traj >= 2048 && a.n_traj < 65536 && a.opts.variant == SBM_VARIANT_AUTO) {
-        constexpr int SEG = M::NV <= 16 ? 16 : 32;
-        dim3 grid((a.n_traj + 64 / SEG - 1) / (64 / SEG)), block(64);
-        if (a.opts.method == SBM_DOPRI45)
-          hipLaunchKernelGGL((sbm_state_packed_kernel<M, SBM_DOPRI45, SEG>), grid, block, 0, stream, a);
-        else
-          hipLaunchKernelGGL((sbm_state_packed_kernel<M, SBM_RK4_FIXED, SEG>), grid, block, 0, stream, a);
+        // DOPRI45 reduces its error norm inside a segment: widths 16 / 32 (DPP).  Segment sums through LDS for
+        // other widths were tried (20 lanes: three trajectories per wavefront): 0.53 against 0.49 ms -- the LDS
+        // round trip per step and a third trajectory to wait for cost more than the denser packing gains.
+        // RK4 reduces nothing: the width is the state variables rounded up to a multiple of four lanes.
+        constexpr int SEG_A = M::NV <= 16 ? 16 : 32;
+        constexpr int SEG_F = (M::NV + 3) / 4 * 4;
+        if (a.opts.method == SBM_DOPRI45) {
+          dim3 grid((a.n_traj + 64 / SEG_A - 1) / (64 / SEG_A)), block(64);
+          hipLaunchKernelGGL((sbm_state_packed_kernel<M, SBM_DOPRI45, SEG_A>), grid, block, 0, stream, a);
+        } else {
+          dim3 grid((a.n_traj + 64 / SEG_F - 1) / (64 / SEG_F)), block(64);
+          hipLaunchKernelGGL((sbm_state_packed_kernel<M, SBM_RK4_FIXED, SEG_F>), grid, block, 0, stream, a);
+        }
         return (int)hipGetLastError();
       }
     }
