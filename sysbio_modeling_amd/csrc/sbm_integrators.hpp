@@ -277,7 +277,13 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
   constexpr int CPL = Sys::CPL;
   using namespace dp;
   const double rtol = o.rtol, atol = o.atol;
-  const int max_steps = o.max_steps > 0 ? o.max_steps : 1000000;
+  // max_steps < 0: a budget of |max_steps| attempts with an early exit -- a trajectory whose CURRENT step size
+  // would need more than four budgets for the rest of the time span gives up at once (checked every 256
+  // attempts from the 512th on, when the controller has settled).  That is the explicit method on a stiff
+  // system, its step size pinned by stability: method='auto' hands such trajectories to the implicit
+  // integrator without first burning the whole budget on them.
+  const bool early_exit = o.max_steps < 0;
+  const int max_steps = o.max_steps > 0 ? o.max_steps : (o.max_steps < 0 ? -o.max_steps : 1000000);
 
   double k1[CPL][NVX], k2[CPL][NVX], k3[CPL][NVX], k4[CPL][NVX], k5[CPL][NVX], k6[CPL][NVX], zt[CPL][NVX];
   // defined values everywhere from the start: lanes / elements that carry no equation must hold
@@ -326,6 +332,9 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
     const double target = t_out[io];
     while (!failed && t < target) {
       if (n_try >= max_steps) { out.status = SBM_MAX_STEPS; failed = true; break; }
+      if (early_exit && n_try >= 512 && (n_try & 255) == 0 && (o.t0 + t_span - t) > 4.0 * max_steps * h) {
+        out.status = SBM_MAX_STEPS; failed = true; break;
+      }
       ++n_try;
       // clip to land on the output time
       double hs = h;

@@ -627,7 +627,7 @@ class Project(object):
         else:
             budget = int(o.get('max_steps') or 0) or 50000
             out, st, steps, stiff = _control.with_stiff_fallback(
-                lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=budget,
+                lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=-budget,
                                                   rtol=rtol, atol=atol, extrapolate=0, **keep)),
                 controlled if self._model.n_vars <= 64 else None, V)
         out['status'] = torch.as_tensor(st, dtype=torch.int32, device=th.device)

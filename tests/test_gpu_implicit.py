@@ -217,6 +217,17 @@ def test_auto_method_switches_stiff_vectors_to_the_implicit_integrator(gpu_model
     assert parity_err(Y[1, 1:], Yr) <= 1.0
     S1 = m.calc_jacobian_batch(P[1:], t_out)                 # plain DOPRI45: the very same numbers
     assert np.array_equal(S[1], S1[0])
+    # the explicit attempt gives up early on the stiff vector (negative max_steps: budget with early exit) instead of
+    # burning its budget, and is untouched on the mild one
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Yq = m.simulate_batch(P, t_out, method='dopri45', max_steps=-20000)
+        early = m.last_info['n_steps'].copy()
+        st_early = m.last_info['status'].copy()
+        m.simulate_batch(P[:1], t_out, method='dopri45', max_steps=20000)
+        full = m.last_info['n_steps'].copy()
+    assert st_early.tolist() == [1, 0] and early[0] <= 1024 and full[0] >= 15000
+    assert np.array_equal(Yq[1], m.simulate_batch(P[1:], t_out)[0])
     # state-only path, and a model that is not stiff at all: nothing switches
     Ys = m.simulate_batch(P, t_out, method='auto', max_steps=20000)
     assert m.last_info['stiff'].tolist() == [True, False] and parity_err(Ys[0, 1:], g['Y'][0]) <= 1.0
