@@ -1667,9 +1667,15 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     constexpr bool kRowsOk = (M::NV <= 256);   // up to four state rows per lane
     // one trajectory per LANE keeps NV stage-vector rows per lane: beyond 64 rows only the rows kernel is built
     constexpr bool kLaneBuilt = !(kRowsOk && M::NV > 64);
+    // Which state-only kernel (measured on cascade20, DOPRI45, scripts/dev_state_big.py): one trajectory per
+    // wavefront up to 2047 trajectories (0.2 ms per 1024, lowest latency); several per wavefront from there
+    // (0.14 ms per 1024: 0.56 ms at 4096, 3.3 ms at 32768); one trajectory per LANE costs 2.6 - 2.9 ms whatever
+    // the batch up to 65536 (one serial chain per lane, 64 of them per wavefront) and wins from ~20000 on --
+    // for small models only: beyond 32 state variables its stage vectors leave the register file.
+    constexpr int kLaneFrom = (M::NV <= 32) ? 20480 : 65536;
     // several trajectories per wavefront once the chip is full: models of up to 32 state variables
     if constexpr (M::NV <= 32 && M::NV >= 2) {
-      if (a.n_traj >= 2048 && a.n_traj < 65536 && a.opts.variant == SBM_VARIANT_AUTO) {
+      if (a.n_traj >= 2048 && a.n_traj < kLaneFrom && a.opts.variant == SBM_VARIANT_AUTO) {
         // DOPRI45 reduces its error norm inside a segment: widths 16 / 32 (DPP).  Segment sums through LDS for
         // other widths were tried (20 lanes: three trajectories per wavefront): 0.53 against 0.49 ms -- the LDS
         // round trip per step and a third trajectory to wait for cost more than the denser packing gains.
@@ -1687,7 +1693,8 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
       }
     }
     if constexpr (kRowsOk) {
-      if ((a.n_traj < 65536 && a.opts.variant != SBM_VARIANT_PER_WAVE) || !kLaneBuilt) {
+      if (((a.n_traj < kLaneFrom || a.opts.variant == SBM_VARIANT_ROW_LANE || a.opts.variant == SBM_VARIANT_ROW_GROUP) &&
+           a.opts.variant != SBM_VARIANT_PER_WAVE) || !kLaneBuilt) {
         dim3 grid(a.n_traj), block(64);
         if (a.opts.method == SBM_DOPRI45)
           hipLaunchKernelGGL((sbm_state_rows_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
