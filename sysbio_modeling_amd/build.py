@@ -97,12 +97,22 @@ def build_c_rhs(name, c_source, force=False):
     so_path = os.path.join(GEN_DIR, 'rhs_%s_%s.so' % (name, digest))
     if os.path.exists(so_path) and not force:
         return so_path
-    with open(c_path, 'w') as fh:
-        fh.write(c_source)
     cc = shutil.which('gcc') or shutil.which('cc')
     if cc is None:
         raise BuildError("no C compiler for the oracle RHS")
-    _run([cc, '-O2', '-fPIC', '-shared', '-o', so_path, c_path, '-lm'], 'build of C RHS %s' % name)
+    # several processes may want the same library at once (worker pools of the CPU baselines): each builds
+    # under private names and moves the result into place atomically
+    tag = '.%d.tmp' % os.getpid()
+    with open(c_path + tag + '.c', 'w') as fh:
+        fh.write(c_source)
+    try:
+        _run([cc, '-O2', '-fPIC', '-shared', '-o', so_path + tag, c_path + tag + '.c', '-lm'], 'build of C RHS %s' % name)
+        os.replace(c_path + tag + '.c', c_path)
+        os.replace(so_path + tag, so_path)
+    finally:
+        for leftover in (c_path + tag + '.c', so_path + tag):
+            if os.path.exists(leftover):
+                os.remove(leftover)
     return so_path
 
 
@@ -112,6 +122,8 @@ def write_generated_header(name, hip_source):
     digest = hashlib.sha1(hip_source.encode()).hexdigest()[:12]
     path = os.path.join(GEN_DIR, '%s_%s.hpp' % (name, digest))
     if not os.path.exists(path):
-        with open(path, 'w') as fh:
+        tmp = '%s.%d.tmp' % (path, os.getpid())
+        with open(tmp, 'w') as fh:
             fh.write(hip_source)
+        os.replace(tmp, path)
     return path, digest
