@@ -19,11 +19,9 @@ skipped (reference :137-139, emit order :185-195).
 from __future__ import annotations
 
 import inspect
-import io
 import re
 from collections import OrderedDict
 
-import sympy
 from sympy import Symbol, sympify, diff, cse
 
 _CATEGORIES = OrderedDict([
