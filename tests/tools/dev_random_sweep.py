@@ -12,16 +12,17 @@ from sysbio_modeling_amd.model import OdeModel
 from oracle import odeint_oracle as oo
 
 n_models = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+n_lo, n_hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3, 25)   # species per network
 rng0 = np.random.default_rng(2026)
 worst = 0.0
 for k in range(n_models):
-    seed, n = int(rng0.integers(10, 10000)), int(rng0.integers(3, 25))
+    seed, n = int(rng0.integers(10, 10000)), int(rng0.integers(n_lo, n_hi))
     gm = GeneratedModel(ns['_random_network'](seed, n))
     m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=gm.spec.name)
     rng = np.random.default_rng(seed)
     P = np.exp(rng.uniform(np.log(0.2), np.log(2.0), (3, len(gm.param_order))))
     t = np.linspace(0, 20.0, 1000); idx = np.array([0, 333, 999])
-    Yr = oo.simulate(gm, P[1], t)[idx]; Sr = oo.calc_jacobian(gm, P[1], t)[idx]
+    Yr = oo.simulate(gm, P[1], t, use_c=True)[idx]; Sr = oo.calc_jacobian(gm, P[1], t, use_c=True)[idx]
     errs = []
     for variant in ('per_wave', 'row_lane', 'row_group'):
         S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant)
