@@ -367,7 +367,7 @@ def main():
             "failed_vectors": int((st5 != 0).sum().item())}
 
         # A model beyond one row / one column per lane: 70 states, 140 parameters, 9870 coupled ODEs per trajectory
-        # (two state rows per lane, sensitivity columns in 12 chunks of 12, one wavefront each).  The plugin is
+        # (two state rows per lane, sensitivity columns in 14 chunks of 10, one wavefront each).  The plugin is
         # built here (hipcc, ~15 s); a failure to build must not cost the headline line.
         try:
             from sysbio_modeling_amd.symbolic import GeneratedModel

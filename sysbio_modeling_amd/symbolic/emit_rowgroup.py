@@ -44,7 +44,7 @@ from __future__ import annotations
 
 
 REG_ELEMS = 15      # elements per lane up to which DOPRI45's stage vectors fit 256 registers (two waves per SIMD)
-AGPR_ELEMS = 34     # ... up to which they fit 512 (one wave per SIMD, v_accvgpr traffic); beyond: scratch
+AGPR_ELEMS = 26     # ... up to which they fit 512 together with the operands (one wave per SIMD, v_accvgpr traffic); beyond: scratch
 MAX_ROWS_PER_LANE = 4
 STATE_COST = 5      # work of the per-chunk state evaluation, in elements per lane
 
@@ -68,7 +68,8 @@ def _best_split(n, ncols, g_min, max_lanes=64):
 
 
 def _cost(elems, nch, rpl=1):
-    spill = 1.0 if elems + rpl <= REG_ELEMS + 1 else (1.6 if elems <= AGPR_ELEMS else 4.0)
+    # the kernel runs two wavefronts per SIMD when elements + state rows per lane <= REG_ELEMS (SBM_RG_MIN_WAVES)
+    spill = 1.0 if elems + rpl <= REG_ELEMS else (1.6 if elems <= AGPR_ELEMS else 4.0 * elems / AGPR_ELEMS)
     return nch * (elems + STATE_COST * rpl) * spill
 
 
@@ -80,7 +81,7 @@ def plan(n, nk, max_lanes=64):
         return None
     rpl = -(-n // max_lanes)           # state rows per lane: rows lane, lane + 64, ...
     best = None
-    for nch in range(1, 65):
+    for nch in range(1, 257):
         if nch > nk:
             break
         ncols = -(-nk // nch)

@@ -276,7 +276,7 @@ def test_rowgroup_plan():
     assert plan(40, 80)[4] > 1 and plan(50, 50)[4] > 1
 
 
-@pytest.mark.parametrize('n_states,n_chunks', [(40, 5), (70, 12)])
+@pytest.mark.parametrize('n_states,n_chunks', [(40, 5), (70, 14)])
 def test_rowgroup_column_chunks_on_host(tmp_path, n_states, n_chunks):
     """Cascades beyond one column per lane (40 states / 80 parameters) and beyond one state row per lane (70 /
     140): the chunked row-group form, emulated lane by lane and chunk by chunk, equals the Python emitter's
