@@ -18,3 +18,19 @@ for name, fn in (('residuals', lambda: proj.residuals(th)), ('calc_project_jacob
     for _ in range(20):
         fn()
     print("%-24s %.2f ms per call" % (name, (time.perf_counter() - t0) / 20 * 1e3))
+
+# where the time of one residuals() call goes: kernel time by events around the C call alone
+import torch
+from sysbio_modeling_amd import _lib
+import ctypes
+th_d = torch.from_numpy(np.asarray(th)[None, :]).cuda()
+for jac in (False, True):
+    o = proj.evaluate_batch(th_d, jacobian=jac, want=('jacobian',) if jac else ('residuals',))
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); a.record()
+    for _ in range(20):
+        o = proj.evaluate_batch(th_d, jacobian=jac, want=('jacobian',) if jac else ('residuals',))
+    b.record(); torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 20 * 1e3
+    print("evaluate_batch(device tensor, V=1, jacobian=%s): wall %.3f ms per call, GPU busy %.3f ms per call" % (jac, wall, a.elapsed_time(b) / 20))

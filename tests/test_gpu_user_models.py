@@ -107,6 +107,14 @@ def test_more_sensitivity_columns_than_lanes():
     y0 = np.concatenate([np.full(35, 0.3), S0.ravel()])
     S_ic = m.calc_jacobian_batch(P[:1], np.array([0.0, 1.0]), init_conditions=y0)
     assert np.array_equal(S_ic[0, 0], S0.ravel())
+    # a failing vector is reported once for all its chunks (worst status), its rows are NaN, its neighbours untouched
+    Pbad = P.copy()
+    Pbad[1, 3] = np.nan
+    with pytest.warns(UserWarning, match='integration failed for 1 of 3'):
+        Sb = m.calc_jacobian_batch(Pbad, t[idx])
+    assert m.last_info['status'].tolist()[0] == 0 and m.last_info['status'][1] != 0 and m.last_info['status'][2] == 0
+    S_ref = m.calc_jacobian_batch(P, t[idx])
+    assert np.all(np.isnan(Sb[1, 1:])) and np.array_equal(Sb[0], S_ref[0]) and np.array_equal(Sb[2], S_ref[2])
 
 
 def test_project_on_a_model_with_more_parameters_than_lanes():
