@@ -67,7 +67,7 @@ typedef struct sbm_integrator_opts {
   double t0;         /* time of the initial condition; output times must be >= t0.
                       * odeint takes t_sim[0] for it (model/ode_model.py:122,167);
                       * Project always integrates from 0 (base_project.py:419)     */
-  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE | _ROW_GROUP */
+  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE | _ROW_GROUP | _SMALL_BATCH */
   int32_t step_mult; /* fixed-step methods: every output interval is cut into
                       * step_mult * ceil(dt / h0) equal steps (0 = 1).  Doubling it halves every
                       * step exactly, which is what Richardson extrapolation needs.          */
@@ -93,7 +93,13 @@ typedef struct sbm_integrator_opts {
  * kernel (models up to 64 state variables), AUTO the one-trajectory-per-wavefront kernel
  * up to 2047 trajectories and its packed form (two or four trajectories per wavefront,
  * bit-identical results) beyond, ROW_LANE / ROW_GROUP always the unpacked one. */
-enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2, SBM_VARIANT_ROW_GROUP = 3 };
+enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2, SBM_VARIANT_ROW_GROUP = 3,
+       /* AUTO, except that the ROW_GROUP kernel takes its small-batch split -- more, smaller column chunks, fewer
+        * equations per lane: the work of ONE wavefront per step is what a call with a single parameter vector
+        * waits for -- while n_traj x chunks <= 1024 (a SIMD each).  The two splits take different step sequences:
+        * results agree to the integration tolerance, not bit for bit, which is why AUTO never switches by itself
+        * (a batch call's rows do not depend on the size of the batch). */
+       SBM_VARIANT_SMALL_BATCH = 4 };
 
 /* per-trajectory status written next to the results (the reference does not
  * check LSODA failures, model/ode_model.py:122,167; non-zero statuses are what

@@ -133,7 +133,7 @@ def dev_ptr(t):
 
 IMPLICIT_GRADED = ('implicit_midpoint_graded', 'imid_graded')
 FIXED_STEP_IMPLICIT = ('implicit_midpoint', 'imid', 'midpoint') + IMPLICIT_GRADED
-VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3}
+VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3, 'small_batch': 4}
 
 
 def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None, t0=0.0,

@@ -24,6 +24,7 @@
 // The generated model header must define `struct SbmModel` (see
 // sysbio_modeling_amd/symbolic/emit.py::emit_hip) and may use SBM_RCP.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1065,41 +1066,41 @@ __global__ void __launch_bounds__(64) sbm_state_packed_kernel(sbm_kernel_args a)
 // table JYL instead of v_readlane scalars) and terms that cross a group boundary go through an LDS
 // halo (emit_rowgroup.py).  Still a 64-thread workgroup: wave-local LDS ordering, no barriers.
 //
-// Column chunks (M::RG_NCH > 1): the columns of S are coupled only through the state, so a trajectory with
+// Column chunks (L::RG_NCH > 1; L = the layout, M::RG0 or M::RG1): the columns of S are coupled only through the state, so a trajectory with
 // more columns than one wavefront can hold in registers is cut into RG_NCH chunks of C*CPL columns;
 // blockIdx.y = chunk, each chunk integrates (state, its columns) on its own -- own error norm, own step
 // sequence, nothing exchanged.  Chunk 0 stores the state; status / step counts are combined with atomicMax
 // (the launcher zeroes them first).
 // ===========================================================================
-template <class M>
+template <class M, class L>
 struct SbmRowGroupShared {
   // JYL rows: G groups of RPG (the last one padded), then one more all-padding group for the idle
   // lanes (>= G*C): nothing is ever written there, it stays zero
-  static constexpr int NPAD = M::RG_G * M::RG_RPG;
-  static constexpr int NROWS = NPAD + M::RG_RPG;
-  static constexpr int LS = M::RG_LS;    // A / H are [local row][lane][cc]; element (i, j) at M::rg_pos(i, j)
-  static constexpr int ZPOS = M::RG_RPG * LS;   // a slot of H that stays zero (absent halo terms)
+  static constexpr int NPAD = L::RG_G * L::RG_RPG;
+  static constexpr int NROWS = NPAD + L::RG_RPG;
+  static constexpr int LS = L::RG_LS;    // A / H are [local row][lane][cc]; element (i, j) at L::rg_pos(i, j)
+  static constexpr int ZPOS = L::RG_RPG * LS;   // a slot of H that stays zero (absent halo terms)
   static constexpr int RPL = (M::NV + 63) / 64;   // state rows per lane (rows lane, lane + 64, ...)
   double Y[64 * RPL];                    // stage state, one component per (row lane, r)
-  alignas(16) double JYL[NROWS * M::RG_JYS + 2];   // J_y coefficients [row][term] (+ spare slot)
-  alignas(16) double A[M::RG_RPG * LS + 2];        // J_p entries (+ spare slot); idle / padded slots stay 0
-  alignas(16) double H[M::RG_RPG * LS + 4];        // published rows of the stage vector (+ zero slot)
+  alignas(16) double JYL[NROWS * L::RG_JYS + 2];   // J_y coefficients [row][term] (+ spare slot)
+  alignas(16) double A[L::RG_RPG * LS + 2];        // J_p entries (+ spare slot); idle / padded slots stay 0
+  alignas(16) double H[L::RG_RPG * LS + 4];        // published rows of the stage vector (+ zero slot)
 };
 
 // EARLY: fetch the lane's A / J_y operands right after the row lanes published them (eval) instead of
 // in finish, so that the column rows of the stage vector are formed while they are in flight.  Costs
 // 2*(NV + RPG*JYS) more live VGPRs: pays for RK4 (18.0 vs 19.4 ms), spills for DOPRI45 (20.7 vs 7.5 ms).
-template <class M, bool EARLY>
+template <class M, class L, bool EARLY>
 struct RowGroupSystem {
-  static constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG;
-  static constexpr int NV = M::RG_RPG * M::RG_CPL;   // elements of S this lane integrates
+  static constexpr int G = L::RG_G, C = L::RG_C, RPG = L::RG_RPG;
+  static constexpr int NV = L::RG_RPG * L::RG_CPL;   // elements of S this lane integrates
   static constexpr int RPL = (M::NV + 63) / 64;      // state rows this lane evaluates: lane, lane + 64, ...
   static constexpr int NVX = NV + RPL;               // + this lane's own state component(s)
   static constexpr int CPL = 1;
-  static constexpr int NCS = M::RG_CPL;
-  __device__ __forceinline__ static constexpr int col_of(int, int i) { return i / M::RG_RPG; }
-  static constexpr int NH = M::RG_NHALO > 0 ? M::RG_NHALO : 1;
-  SbmRowGroupShared<M>* sh;
+  static constexpr int NCS = L::RG_CPL;
+  __device__ __forceinline__ static constexpr int col_of(int, int i) { return i / L::RG_RPG; }
+  static constexpr int NH = L::RG_NHALO > 0 ? L::RG_NHALO : 1;
+  SbmRowGroupShared<M, L>* sh;
   int lane, grp, cp;             // lane = grp*C + cp on the active lanes
   int cbase;                     // first column of this wavefront's chunk
   bool active;                   // lane < G*C
@@ -1117,7 +1118,7 @@ struct RowGroupSystem {
 
   struct Token {
     double f[RPL];
-    double acol[EARLY ? NV : 1], coef[EARLY ? RPG * M::RG_JYS : 1];
+    double acol[EARLY ? NV : 1], coef[EARLY ? RPG * L::RG_JYS : 1];
   };
   struct Pending { double ys[RPL][M::RL_MAXYS]; };
   __device__ __forceinline__ Pending issue(double /*t*/, const double (&z)[1][NVX]) const {
@@ -1155,7 +1156,7 @@ struct RowGroupSystem {
     }
     lds_order();
     if constexpr (EARLY) {
-      M::load_rowgroup(a_lane, jy_lane, k.acol, k.coef);
+      L::load_rowgroup(a_lane, jy_lane, k.acol, k.coef);
       lds_order();
     }
     return k;
@@ -1165,14 +1166,14 @@ struct RowGroupSystem {
     double zc[NV], dc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) zc[i] = z[0][i];
-    M::publish_rowgroup(h_lane, zc);
+    L::publish_rowgroup(h_lane, zc);
     lds_order();
     if constexpr (EARLY) {
-      M::apply_rowgroup(k.acol, k.coef, sh->H, hoff, zc, dc);
+      L::apply_rowgroup(k.acol, k.coef, sh->H, hoff, zc, dc);
     } else {
-      double acol[NV], coef[RPG * M::RG_JYS];
-      M::load_rowgroup(a_lane, jy_lane, acol, coef);
-      M::apply_rowgroup(acol, coef, sh->H, hoff, zc, dc);
+      double acol[NV], coef[RPG * L::RG_JYS];
+      L::load_rowgroup(a_lane, jy_lane, acol, coef);
+      L::apply_rowgroup(acol, coef, sh->H, hoff, zc, dc);
     }
     lds_order();
 #pragma unroll
@@ -1201,7 +1202,7 @@ struct RowGroupSystem {
         src = src >= G * C ? src - G * C : src;
         tot += __shfl(v, active ? src : lane, 64);
       }
-      const bool has_col = active && ((M::RG_NCH > 1 ? cbase : 0) + cp + C * cc < M::NK);
+      const bool has_col = active && ((L::RG_NCH > 1 ? cbase : 0) + cp + C * cc < M::NK);
       m = fmaxf(m, has_col ? tot : 0.f);
     }
     const float x = (lane < M::NV) ? sbm_nan_to_inf(xsum) : 0.f;
@@ -1212,20 +1213,20 @@ struct RowGroupSystem {
   __device__ __forceinline__ double sum(double v) const { return sbm_wave_sum(v); }
 };
 
-template <class M, int METHOD>
+template <class M, class L, int METHOD>
 // Two waves per SIMD (256 registers each) when the lane's share of S is small enough for DOPRI45's seven
 // stage vectors to fit: 2*(RPG*CPL + 1)*7 + operands <= 256 holds up to 15 elements (cascade20: 14 + 1).
 // Larger shares get the whole register file (one wave per SIMD) rather than spill.
 #ifndef SBM_RG_MIN_WAVES
-#define SBM_RG_MIN_WAVES ((M::RG_RPG * M::RG_CPL + (M::NV + 63) / 64 <= 15 || METHOD == SBM_RK4_FIXED) ? 2 : 1)
+#define SBM_RG_MIN_WAVES ((L::RG_RPG * L::RG_CPL + (M::NV + 63) / 64 <= 15 || METHOD == SBM_RK4_FIXED) ? 2 : 1)
 #endif
 __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel(sbm_kernel_args a) {
-  using Sys = RowGroupSystem<M, METHOD == SBM_RK4_FIXED>;
-  using Sh = SbmRowGroupShared<M>;
+  using Sys = RowGroupSystem<M, L, METHOD == SBM_RK4_FIXED>;
+  using Sh = SbmRowGroupShared<M, L>;
   constexpr int MNV = M::NV, NK = M::NK;
-  constexpr int G = M::RG_G, C = M::RG_C, RPG = M::RG_RPG, CPL = M::RG_CPL;
+  constexpr int G = L::RG_G, C = L::RG_C, RPG = L::RG_RPG, CPL = L::RG_CPL;
   constexpr int NE = Sys::NV, NVX = Sys::NVX, NPAD = Sh::NPAD;
-  constexpr int NCH = M::RG_NCH;
+  constexpr int NCH = L::RG_NCH;
   constexpr int RPL = Sys::RPL;
   static_assert(G * C <= 64 && C * CPL * NCH >= NK && C * CPL * (NCH - 1) < NK && NPAD >= MNV, "row-group layout");
   __shared__ Sh sh;
@@ -1239,7 +1240,7 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   constexpr int LS = Sh::LS;
   for (int i = lane; i < RPG * LS + 2; i += 64) sh.A[i] = 0.0;
   for (int i = lane; i < RPG * LS + 4; i += 64) sh.H[i] = 0.0;
-  for (int i = lane; i < NROWS * M::RG_JYS + 2; i += 64) sh.JYL[i] = 0.0;
+  for (int i = lane; i < NROWS * L::RG_JYS + 2; i += 64) sh.JYL[i] = 0.0;
 #pragma unroll
   for (int r = 0; r < RPL; ++r) sh.Y[lane + 64 * r] = 0.0;
 
@@ -1262,27 +1263,27 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
     for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[r][s] = P[M::rl_ps(s, row)];
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJY; ++s) {
-      const int jp_ = M::rg_jypos(s, row);
-      sys.jypos[r][s] = (has_row && jp_ < NPAD * M::RG_JYS) ? jp_ : NROWS * M::RG_JYS + 1;   // else: spare slot
+      const int jp_ = L::rg_jypos(s, row);
+      sys.jypos[r][s] = (has_row && jp_ < NPAD * L::RG_JYS) ? jp_ : NROWS * L::RG_JYS + 1;   // else: spare slot
     }
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) {
       if constexpr (NCH == 1 && RPL == 1) {
         const int ap = M::rl_apos(s, row);                      // row*64 + column; unused slots carry MNV*64
-        sys.apos[r][s] = (has_row && ap < MNV * 64) ? M::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1;
+        sys.apos[r][s] = (has_row && ap < MNV * 64) ? L::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1;
       } else {
         const int lc = M::rl_jpcol(s, row) - cbase;             // column within this chunk (unused slots: -1)
-        sys.apos[r][s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? M::rg_pos(row, lc) : RPG * LS + 1;
+        sys.apos[r][s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? L::rg_pos(row, lc) : RPG * LS + 1;
       }
     }
   }
   sys.a_lane = sh.A + CPL * lane;
-  sys.jy_lane = sh.JYL + (sys.grp * RPG) * M::RG_JYS;
+  sys.jy_lane = sh.JYL + (sys.grp * RPG) * L::RG_JYS;
   sys.h_lane = sh.H + CPL * lane;
 #pragma unroll
   for (int t = 0; t < Sys::NH; ++t) {
-    const int src = (M::RG_NHALO > 0 && sys.active) ? M::rg_hsrc(t, sys.grp) : NPAD;   // NPAD: term absent
-    sys.hoff[t] = src < NPAD ? M::rg_pos(src, sys.cp) : Sh::ZPOS;
+    const int src = (L::RG_NHALO > 0 && sys.active) ? L::rg_hsrc(t, sys.grp) : NPAD;   // NPAD: term absent
+    sys.hoff[t] = src < NPAD ? L::rg_pos(src, sys.cp) : Sh::ZPOS;
   }
   __syncthreads();
 
@@ -1599,6 +1600,9 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
 // ---------------------------------------------------------------------------
 // host-side launcher used by sbm_plugin_main.hip
 // ---------------------------------------------------------------------------
+template <class T>
+struct SbmTypeTag { using type = T; };
+
 template <class M>
 static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t stream) {
   const sbm_kernel_args a = *args;
@@ -1621,30 +1625,42 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     // and 17 rows: 1.6x faster than per-wave)
     constexpr bool kRowLaneOk = (M::NV <= 64 && M::NK <= 64);
     constexpr bool kRowLanePays = kRowLaneOk;
-    constexpr bool kRowGroupOk = M::RG_OK;   // any number of columns (chunks of them), up to four rows per lane
+    constexpr bool kRowGroupOk = M::RG0::RG_OK;   // any number of columns (chunks of them), up to four rows per lane
     // The per-wave kernel keeps all NV rows of ceil((NK+1)/64) columns on every lane: for a large model that is
     // minutes of compile time for a kernel whose stage vectors live in scratch.  Where the row-group form exists
     // it is not instantiated beyond 4096 sensitivity entries, and opts.variant becomes a no-op for that model.
     constexpr bool kPerWaveBuilt = !(kRowGroupOk && M::NV * (M::NK + 1) > 4096);
     const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
-                         (a.opts.variant == SBM_VARIANT_AUTO && kRowLanePays);
+                         ((a.opts.variant == SBM_VARIANT_AUTO || a.opts.variant == SBM_VARIANT_SMALL_BATCH) && kRowLanePays);
     // row-group kernel: the row-lane kernel with the rows of a column split over several lanes,
     // when the emitter found a split that cuts the elements per lane (M::RG_OK)
     if constexpr (kRowGroupOk) {
-      if (a.opts.variant == SBM_VARIANT_ROW_GROUP || a.opts.variant == SBM_VARIANT_AUTO || !kPerWaveBuilt) {
-        dim3 grid(a.n_traj, M::RG_NCH), block(64);
-        if constexpr (M::RG_NCH > 1) {
-          hipError_t e = hipSuccess;
-          if (a.status) e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
-          if (e == hipSuccess && a.n_steps) e = hipMemsetAsync(a.n_steps, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
-          if (e == hipSuccess && a.n_reject) e = hipMemsetAsync(a.n_reject, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
-          if (e != hipSuccess) return (int)e;
-        }
-        if (a.opts.method == SBM_DOPRI45)
-          hipLaunchKernelGGL((sbm_sens_rowgroup_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
-        else
-          hipLaunchKernelGGL((sbm_sens_rowgroup_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
-        return (int)hipGetLastError();
+      if (a.opts.variant == SBM_VARIANT_ROW_GROUP || a.opts.variant == SBM_VARIANT_AUTO ||
+          a.opts.variant == SBM_VARIANT_SMALL_BATCH || !kPerWaveBuilt) {
+        // Two splits of the same form (emit_rowgroup.py): RG0 for throughput; RG1 -- more, smaller column chunks,
+        // fewer elements per lane -- while its wavefronts still find an empty SIMD each (1024 of them): a single
+        // parameter vector, a serial optimiser's call, is latency-bound and extra wavefronts are free.
+        // Opt-in (SBM_VARIANT_SMALL_BATCH: what the single-vector methods of the Python classes ask for): the two
+        // splits take different step sequences, and a batch call's rows must not depend on how many rows it has.
+        const bool small_batch = !std::is_same<typename M::RG1, typename M::RG0>::value &&
+                                 a.opts.variant == SBM_VARIANT_SMALL_BATCH && (long long)a.n_traj * M::RG1::RG_NCH <= 1024;
+        auto go = [&](auto layout_tag) -> int {
+          using L = typename decltype(layout_tag)::type;
+          dim3 grid(a.n_traj, L::RG_NCH), block(64);
+          if constexpr (L::RG_NCH > 1) {
+            hipError_t e = hipSuccess;
+            if (a.status) e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+            if (e == hipSuccess && a.n_steps) e = hipMemsetAsync(a.n_steps, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+            if (e == hipSuccess && a.n_reject) e = hipMemsetAsync(a.n_reject, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+            if (e != hipSuccess) return (int)e;
+          }
+          if (a.opts.method == SBM_DOPRI45)
+            hipLaunchKernelGGL((sbm_sens_rowgroup_kernel<M, L, SBM_DOPRI45>), grid, block, 0, stream, a);
+          else
+            hipLaunchKernelGGL((sbm_sens_rowgroup_kernel<M, L, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+          return (int)hipGetLastError();
+        };
+        return small_batch ? go(SbmTypeTag<typename M::RG1>{}) : go(SbmTypeTag<typename M::RG0>{});
       }
     }
     if constexpr (kRowLaneOk) {

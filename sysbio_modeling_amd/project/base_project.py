@@ -695,10 +695,17 @@ class Project(object):
     # ------------------------------------------------------------------
     # public objective functions  (reference :708-892)
     # ------------------------------------------------------------------
+    def _single(self):
+        """Integrator overrides of the single-vector methods below -- what a serial optimiser calls (the reference's
+        leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)): one parameter vector leaves the chip
+        empty, so the sensitivity kernel takes its small-batch split unless the project's options name a variant.
+        Results equal the corresponding row of a batch call to the integration tolerance, not bit for bit."""
+        return {} if 'variant' in self.integrator_options else {'variant': 'small_batch'}
+
     def residuals(self, project_param_vector):
         """(B*sim - data)/sigma for every measurement row, then prior rows; (m,) array."""
         self.reset_calcs()
-        res = self.evaluate_batch(np.asarray(project_param_vector, dtype=float)[None, :])
+        res = self.evaluate_batch(np.asarray(project_param_vector, dtype=float)[None, :], **self._single())
         self._remember(project_param_vector, res, False)
         return res['residuals'][0]
 
@@ -709,7 +716,7 @@ class Project(object):
         """d(B*sim)/d theta, (m, n) array: B*J + sim (x) dB/dtheta (reference :731-771)."""
         self.reset_calcs()
         res = self.evaluate_batch(np.asarray(project_param_vector, dtype=float)[None, :], jacobian=True,
-                                  want=('jacobian', 'model_jacobian', 'sf_gradient'))
+                                  want=('jacobian', 'model_jacobian', 'sf_gradient'), **self._single())
         self._remember(project_param_vector, res, True)
         return res['jacobian'][0]
 
@@ -721,7 +728,7 @@ class Project(object):
         gives both r and J here; the reference integrates three times."""
         self.reset_calcs()
         res = self.evaluate_batch(np.asarray(project_param_vector, dtype=float)[None, :], jacobian=True,
-                                  want=('jacobian', 'model_jacobian', 'gradient', 'sf_gradient'))
+                                  want=('jacobian', 'model_jacobian', 'gradient', 'sf_gradient'), **self._single())
         self._remember(project_param_vector, res, True)
         return res['gradient'][0]
 

@@ -420,7 +420,9 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     nnz_y, nnz_p = max(len(d.jy), 1), max(len(d.jp), 1)
     L = _fmt_header(spec, "//")
     rl_tables, rl_meta = emit_rowlane.emit_rowlane_tables(spec, d, None)
-    rg_tables, rg_layout = emit_rowgroup.emit_tables(spec, d)
+    rg_tables, rg_layout = emit_rowgroup.emit_tables(spec, d, tag='RG0')
+    rg_tables1, rg_layout1 = emit_rowgroup.emit_tables(spec, d, tag='RG1', latency=True)
+    rg_tables = rg_tables + rg_tables1
     im_members, im_meta = emit_implicit.emit_members(spec, d)
     im_tables = emit_implicit.emit_tables(spec, d, im_meta)
     L += ["#pragma once", ""] + rl_tables + rg_tables + im_tables + [
@@ -511,7 +513,8 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     # ---- row-lane form: SIMD across isomorphic equations (emit_rowlane.py) ----
     L += emit_rowlane.emit_rowlane_members(spec, d, rl_meta,
                                            lambda smap: _ExprPrinter(smap, rcp="SBM_RCP(%s)", lang='hip'))
-    L += [""] + emit_rowgroup.emit_members(spec, d, rg_layout)
+    L += [""] + emit_rowgroup.emit_members(spec, d, rg_layout, tag='RG0')
+    L += emit_rowgroup.emit_members(spec, d, rg_layout1, tag='RG1', alias_of='RG0')
     L += [""] + im_members + [
         "  __device__ __forceinline__ static int im_rstart(int row) { return SBM_IM_RSTART[IM_TRI ? row : 0]; }",
         "  __device__ __forceinline__ static int im_diagslot(int row) { return SBM_IM_DIAGSLOT[IM_TRI ? row : 0]; }",

@@ -101,10 +101,47 @@ def plan(n, nk, max_lanes=64):
     return sp[1:] + (nch,)
 
 
-def layout(spec, d):
-    """Term structure of the row-group form.  Returns None when the form does not apply."""
+def plan_latency(n, nk, max_lanes=64, max_chunks=16):
+    """The split for SMALL batches (a serial optimiser evaluating one parameter vector at a time: the reference's
+    leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)): the chip is empty, so extra wavefronts are
+    free and what counts is the work of ONE wavefront per step -- elements per lane plus the state evaluation.
+    More, smaller column chunks (cascade20: four chunks of ten columns, 4 elements per lane instead of 14).
+    Returns (G, C, CPL, RPG, NCH) or None."""
+    if n < 2 or nk < 1 or n > MAX_ROWS_PER_LANE * max_lanes:
+        return None
+    rpl = -(-n // max_lanes)
+    best = None
+    for nch in range(1, max_chunks + 1):
+        if nch > nk:
+            break
+        ncols = -(-nk // nch)
+        if nch > 1 and (nch - 1) * ncols >= nk:
+            continue
+        sp = _best_split(n, ncols, 1, max_lanes)
+        if sp is None:
+            continue
+        key = (sp[0] + STATE_COST * rpl + 0.3 * nch, nch)     # a wavefront's work per step; a small price per chunk
+        if best is None or key < best[0]:
+            best = (key, sp, nch)
+    return None if best is None else best[1][1:] + (best[2],)
+
+
+def latency_plan_or_none(n, nk):
+    """The small-batch split when it differs from the throughput split and keeps a lane's share within the
+    two-wavefronts-per-SIMD budget; None: the throughput split serves small batches too."""
+    p0, p1 = plan(n, nk), plan_latency(n, nk)
+    if p0 is None or p1 is None or p1 == p0:
+        return None
+    if p1[3] * p1[2] + -(-n // 64) > REG_ELEMS or p1[3] * p1[2] >= p0[3] * p0[2]:
+        return None
+    return p1
+
+
+def layout(spec, d, latency=False):
+    """Term structure of the row-group form (``latency``: the small-batch split).  Returns None when the form does
+    not apply (``latency``: or when the throughput split serves small batches as well)."""
     n, nk = spec.n_vars, spec.n_sens
-    p = plan(n, nk)
+    p = latency_plan_or_none(n, nk) if latency else plan(n, nk)
     if p is None:
         return None
     G, C, CPL, RPG, NCH = p
@@ -153,23 +190,33 @@ def layout(spec, d):
                 publish=sorted(publish), jys=jys, jypos=jypos, max_jy=max_jy, n_pad=n_pad)
 
 
-def emit_tables(spec, d):
-    lay = layout(spec, d)
+def emit_tables(spec, d, tag='RG0', latency=False):
+    """Namespace-scope tables of one layout (``tag``: RG0 = throughput split, RG1 = small-batch split)."""
+    lay = layout(spec, d, latency=latency)
     if lay is None:
         return [], None
     n = spec.n_vars
-    L = ["// row-group tables",
-         "__constant__ short SBM_RG_JYPOS[%d] = {%s};   // [slot][row] -> index into JYL" %
-         (lay['max_jy'] * n, ", ".join(str(v) for slot in lay['jypos'] for v in slot))]
+    L = ["// row-group tables, layout %s" % tag,
+         "__constant__ short SBM_%s_JYPOS[%d] = {%s};   // [slot][row] -> index into JYL" %
+         (tag, lay['max_jy'] * n, ", ".join(str(v) for slot in lay['jypos'] for v in slot))]
     nh = max(len(lay['hsrc']), 1)
     flat = [v for t in lay['hsrc'] for v in t] or [lay['n_pad']] * lay['G']
-    L += ["__constant__ short SBM_RG_HSRC[%d] = {%s};   // [halo term][group] -> source row" %
-          (nh * lay['G'], ", ".join(str(v) for v in flat)), ""]
+    L += ["__constant__ short SBM_%s_HSRC[%d] = {%s};   // [halo term][group] -> source row" %
+          (tag, nh * lay['G'], ", ".join(str(v) for v in flat)), ""]
     return L, lay
 
 
-def emit_members(spec, d, lay):
-    """Members of ``struct SbmModel``; with ``lay is None`` only RG_OK = false and inert stubs."""
+def emit_members(spec, d, lay, tag='RG0', alias_of=None):
+    """``struct <tag>`` nested in ``struct SbmModel``: one layout of the row-group form (the kernels are templates
+    over it); with ``lay is None`` only RG_OK = false and inert stubs -- or, with ``alias_of``, another name for
+    that layout."""
+    if lay is None and alias_of is not None:
+        return ["  using %s = %s;   // small batches run the throughput split" % (tag, alias_of)]
+    body = _emit_struct_body(spec, d, lay, tag)
+    return ["  struct %s {" % tag] + body + ["  };"]
+
+
+def _emit_struct_body(spec, d, lay, tag):
     n = spec.n_vars
     if lay is None:
         return ["  // ---- row-group form: does not pay for this model ----",
@@ -196,8 +243,8 @@ def emit_members(spec, d, lay):
          "  __device__ __forceinline__ static int rg_pos(int row, int col) {",
          "    return (row % RG_RPG) * RG_LS + RG_CPL * ((row / RG_RPG) * RG_C + col % RG_C) + col / RG_C;",
          "  }",
-         "  __device__ __forceinline__ static int rg_jypos(int slot, int row) { return SBM_RG_JYPOS[slot * NV + row]; }",
-         "  __device__ __forceinline__ static int rg_hsrc(int term, int group) { return SBM_RG_HSRC[term * RG_G + group]; }",
+         "  __device__ __forceinline__ static int rg_jypos(int slot, int row) { return SBM_%s_JYPOS[slot * NV + row]; }" % tag,
+         "  __device__ __forceinline__ static int rg_hsrc(int term, int group) { return SBM_%s_HSRC[term * RG_G + group]; }" % tag,
          "  // rows other groups read: h_lane = H + CPL*lane",
          "  template <int NZ>",
          "  __device__ __forceinline__ static void publish_rowgroup(double* h_lane, const double (&z)[NZ]) {",

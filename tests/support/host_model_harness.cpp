@@ -8,6 +8,7 @@
 //                       (row-group kernel; returns -1 when the model has no row-group form)
 // Used by tests/test_symbolic.py to pin the HIP text to the Python/C emitters on CPU.
 #include <cmath>
+#include <type_traits>
 #define __device__
 #define __constant__ static const
 #define __forceinline__ inline
@@ -97,19 +98,22 @@ void h_sens_rhs_rowlane(const double* y, double t, double* yout, const double* p
 
 // The row-group kernel's right-hand side, lane by lane: LDS tables are plain arrays here, the
 // per-lane base pointers / halo offsets are set up exactly as sbm_sens_rowgroup_kernel does.
-int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p) {
+}  // extern "C"
+
+template <class L>
+static int sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p) {
   using M = SbmModel;
-  if constexpr (!M::RG_OK) {
+  if constexpr (!L::RG_OK) {
     (void)y; (void)t; (void)yout; (void)p;
     return -1;
   } else {
-    constexpr int N = M::NV, K = M::NK, G = M::RG_G, C = M::RG_C, CPL = M::RG_CPL, RPG = M::RG_RPG, JYS = M::RG_JYS;
+    constexpr int N = M::NV, K = M::NK, G = L::RG_G, C = L::RG_C, CPL = L::RG_CPL, RPG = L::RG_RPG, JYS = L::RG_JYS;
     constexpr int NPAD = G * RPG, NROWS = NPAD + RPG, NE = RPG * CPL;
-    constexpr int NH = M::RG_NHALO > 0 ? M::RG_NHALO : 1;
-    constexpr int LS = M::RG_LS, ZPOS = RPG * LS;
+    constexpr int NH = L::RG_NHALO > 0 ? L::RG_NHALO : 1;
+    constexpr int LS = L::RG_LS, ZPOS = RPG * LS;
     static double A[RPG * LS + 2], H[RPG * LS + 4], JYL[NROWS * JYS + 2];
     // one pass per column chunk (on the device: one wavefront each, blockIdx.y)
-    for (int chunk = 0; chunk < M::RG_NCH; ++chunk) {
+    for (int chunk = 0; chunk < L::RG_NCH; ++chunk) {
     const int cbase = chunk * C * CPL;
     for (double& v : A) v = 0.0;
     for (double& v : H) v = 0.0;
@@ -123,10 +127,10 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
       M::class_dispatch(M::rl_class(row), t, ys, ps, f, jy, jp);
       for (int s = 0; s < M::RL_MAXJP; ++s) {
         const int lc = M::rl_jpcol(s, row) - cbase;
-        A[(lc >= 0 && lc < C * CPL && lc + cbase < K) ? M::rg_pos(row, lc) : RPG * LS + 1] = jp[s];
+        A[(lc >= 0 && lc < C * CPL && lc + cbase < K) ? L::rg_pos(row, lc) : RPG * LS + 1] = jp[s];
       }
       for (int s = 0; s < M::RL_MAXJY; ++s) {
-        const int jpz = M::rg_jypos(s, row);
+        const int jpz = L::rg_jypos(s, row);
         JYL[jpz < NPAD * JYS ? jpz : NROWS * JYS + 1] = jy[s];
       }
       yout[row] = f;
@@ -140,19 +144,19 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
           const int grow = g * RPG + r, col = cbase + cp + C * cc;
           z[lane][r + RPG * cc] = (active && grow < N && col < K) ? y[N + grow * K + col] : 0.0;
         }
-      M::publish_rowgroup(H + CPL * lane, z[lane]);
+      L::publish_rowgroup(H + CPL * lane, z[lane]);
     }
     for (int lane = 0; lane < 64; ++lane) {
       const bool active = lane < G * C;
       const int g = active ? lane / C : G, cp = lane - g * C;
       int hoff[NH];
       for (int tt = 0; tt < NH; ++tt) {
-        const int src = (M::RG_NHALO > 0 && active) ? M::rg_hsrc(tt, g) : NPAD;
-        hoff[tt] = src < NPAD ? M::rg_pos(src, cp) : ZPOS;
+        const int src = (L::RG_NHALO > 0 && active) ? L::rg_hsrc(tt, g) : NPAD;
+        hoff[tt] = src < NPAD ? L::rg_pos(src, cp) : ZPOS;
       }
       double acol[NE], coef[RPG * JYS];
-      M::load_rowgroup(A + CPL * lane, JYL + (g * RPG) * JYS, acol, coef);
-      M::apply_rowgroup(acol, coef, H, hoff, z[lane], dz[lane]);
+      L::load_rowgroup(A + CPL * lane, JYL + (g * RPG) * JYS, acol, coef);
+      L::apply_rowgroup(acol, coef, H, hoff, z[lane], dz[lane]);
       for (int cc = 0; cc < CPL; ++cc)
         for (int r = 0; r < RPG; ++r) {
           const int grow = g * RPG + r, col = cbase + cp + C * cc;
@@ -164,6 +168,17 @@ int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p
     return 0;
   }
 }
+
+extern "C" {
+// throughput layout (RG0) and small-batch layout (RG1: more, smaller column chunks; may be the same type)
+int h_sens_rhs_rowgroup(const double* y, double t, double* yout, const double* p) {
+  return sens_rhs_rowgroup<SbmModel::RG0>(y, t, yout, p);
+}
+int h_sens_rhs_rowgroup_small_batch(const double* y, double t, double* yout, const double* p) {
+  return sens_rhs_rowgroup<SbmModel::RG1>(y, t, yout, p);
+}
+int h_rowgroup_layouts_differ() { return std::is_same<SbmModel::RG0, SbmModel::RG1>::value ? 0 : 1; }
+
 
 // b <- (I - gamma*J_y(y))^-1 b through the generated sparse LU (im_build / im_factor / im_solve)
 void h_im_solve(double gamma, const double* y, double t, const double* p, double* b) {

@@ -293,6 +293,28 @@ def test_full_ensemble_properties(gpu_models):
         assert float(torch.max(torch.abs(fd - s) / (scale + 1e-12))) < 1e-5
 
 
+def test_single_vector_calls_take_the_small_batch_split(gpu_models, golden):
+    """OdeModel.calc_jacobian and the single-vector methods of Project -- what a serial optimiser calls -- run the
+    row-group kernel's small-batch split (cascade20: five chunks of eight columns, 3 equations per lane instead of 14):
+    another step sequence, the same numbers to the parity tolerance; batch calls never switch by themselves, so their
+    rows do not depend on the size of the batch."""
+    m = gpu_models('cascade20')
+    g = golden('cascade20_ref.npz')
+    t_out = _from_zero(g['t'][g['idx']])
+    S1 = m.calc_jacobian(g['P'][0], t_out)
+    steps_single = int(m.last_info['n_steps'][0])
+    Sb = m.calc_jacobian_batch(g['P'], t_out)
+    steps_batch = int(m.last_info['n_steps'][0])
+    assert parity_err(S1[1:], g['S'][0]) <= 1.0 and parity_err(Sb[0][1:], g['S'][0]) <= 1.0
+    assert not np.array_equal(S1, Sb[0]) and steps_single != steps_batch        # two splits, two step sequences
+    assert np.array_equal(m.calc_jacobian_batch(g['P'][:1], t_out)[0], Sb[0])    # a batch of one is still a batch
+    assert np.array_equal(m.calc_jacobian_batch(g['P'][:1], t_out, variant='small_batch')[0], S1)
+    # beyond 1024 wavefronts the request falls back to the throughput split
+    from sysbio_modeling_amd import models_zoo
+    _, P = models_zoo.cascade_ensemble(512)
+    assert np.array_equal(m.calc_jacobian_batch(P, t_out, variant='small_batch'), m.calc_jacobian_batch(P, t_out))
+
+
 @pytest.mark.parametrize('name,n_traj', [('cascade20', 4096), ('cascade20', 2049), ('michaelis_menten', 3003)])
 def test_packed_state_kernel_equals_the_unpacked_one(gpu_models, zoo, name, n_traj):
     """From 2048 trajectories on the state-only path packs several trajectories into one wavefront (two segments of
@@ -525,11 +547,16 @@ def test_project_cascade_vs_oracle(gpu_models, zoo, compat, fixed, priors):
         assert parity_err(out['model_jacobian'][v], po.model_jacobian(thetas[v])) <= 20.0
         assert np.allclose(out['gradient'][v], (Jref.T * ref).sum(axis=1), rtol=1e-5,
                            atol=1e-6 * np.max(np.abs(Jref)))
-    # V = 1 through the reference-named methods gives bit-identical numbers to the batch
-    # (residuals(): state-only kernel; calc_project_jacobian(): augmented kernel)
+    # V = 1 through the reference-named methods: residuals() (state-only kernel) gives bit-identical numbers to the
+    # batch; calc_project_jacobian() runs the augmented kernel's small-batch split (another step sequence) and agrees
+    # to the integration tolerance -- and bit for bit when the project's options pin the variant
     res_only = proj.evaluate_batch(thetas)
     assert np.array_equal(proj.residuals(thetas[1]), res_only['residuals'][1])
+    J1 = proj.calc_project_jacobian(thetas[1])
+    assert np.allclose(J1, out['jacobian'][1], rtol=1e-7, atol=1e-7 * np.max(np.abs(out['jacobian'][1])))
+    proj.integrator_options['variant'] = 'auto'
     assert np.array_equal(proj.calc_project_jacobian(thetas[1]), out['jacobian'][1])
+    del proj.integrator_options['variant']
     # the two kernels agree with each other to the parity tolerance (scaled by 1/sigma)
     assert np.allclose(res_only['residuals'], out['residuals'], rtol=1e-7, atol=2e-7)
 

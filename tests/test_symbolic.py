@@ -145,12 +145,19 @@ def test_hip_text_equals_python_and_c_on_host(name, tmp_path):
         assert rc_ == (-1 if name == 'simple' else 0)
         if rc_ == 0:
             assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
+            # the small-batch layout (more, smaller column chunks) of the same form
+            out = np.zeros(n + n * k)
+            assert lib.h_sens_rhs_rowgroup_small_batch(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp),
+                                                       p.ctypes.data_as(dp)) == 0
+            assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
         ref_s = np.zeros(n)
         gm.model(y[:n].copy(), 0.0, ref_s, p)
         out = np.zeros(n)
         lib.h_rhs(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp), p.ctypes.data_as(dp))
         assert np.allclose(out, ref_s, rtol=1e-13, atol=1e-15)
         assert np.allclose(ref[:n], ref_s, rtol=1e-13, atol=1e-15)
+    # which models have a distinct small-batch layout (Michaelis-Menten: 10 lanes either way)
+    assert lib.h_rowgroup_layouts_differ() == (1 if name in ('cascade20', 'stiff50') else 0)
 
 
 def test_cascade_definition():
@@ -253,10 +260,10 @@ def test_rowgroup_chunks_of_large_irregular_networks_on_host(tmp_path, seed, n):
         p = rng.uniform(0.05, 2.0, len(gm.param_order))
         ref = np.zeros(n + n * k)
         gm.sens_model(y, 0.0, ref, p)
-        out = np.zeros(n + n * k)
-        assert lib.h_sens_rhs_rowgroup(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp),
-                                       p.ctypes.data_as(dp)) == 0
-        assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
+        for fn in (lib.h_sens_rhs_rowgroup, lib.h_sens_rhs_rowgroup_small_batch):
+            out = np.zeros(n + n * k)
+            assert fn(y.ctypes.data_as(dp), ctypes.c_double(0.0), out.ctypes.data_as(dp), p.ctypes.data_as(dp)) == 0
+            assert np.allclose(out, ref, rtol=1e-12, atol=1e-14)
 
 
 def test_rowgroup_plan():
@@ -274,6 +281,13 @@ def test_rowgroup_plan():
         assert C * CPL * NCH >= nk and C * CPL * (NCH - 1) < nk       # every chunk holds a column
         assert RPG * CPL <= 15                                       # DOPRI45's stage vectors fit 256 registers
     assert plan(40, 80)[4] > 1 and plan(50, 50)[4] > 1
+    # small batches: the work of ONE wavefront counts, extra wavefronts are free
+    from sysbio_modeling_amd.symbolic.emit_rowgroup import plan_latency, latency_plan_or_none
+    G, C, CPL, RPG, NCH = plan_latency(20, 40)
+    assert NCH > 1 and RPG * CPL <= 5 and C * CPL * NCH >= 40
+    assert latency_plan_or_none(20, 40) == (G, C, CPL, RPG, NCH)
+    assert latency_plan_or_none(2, 5) is None          # Michaelis-Menten: nothing to gain
+    assert latency_plan_or_none(130, 289) is None      # the small-batch split would leave the register budget
 
 
 @pytest.mark.parametrize('n_states,n_chunks', [(40, 5), (70, 14)])
