@@ -30,6 +30,9 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     clipped to ``max_step`` log-units, and trial integrations get a step budget
     (``max_steps``, default 20000) -- a trial that exhausts it is simply rejected.
 
+    With a handful of starts the chip is mostly empty: ``variant='small_batch'`` (an integrator override) lets the
+    sensitivity kernel use its small-batch split while starts x experiments x chunks <= 1024.
+
     Returns a dict of numpy arrays: theta (V, q), cost (V,) = 0.5 |r|^2, n_iter (V,) iterations until
     convergence (max_iter if never), converged (V,) bool, n_evaluations (total trial points integrated).
     """
