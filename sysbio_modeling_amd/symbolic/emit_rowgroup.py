@@ -67,6 +67,11 @@ def _best_split(n, ncols, g_min, max_lanes=64):
     return best
 
 
+# Calibration of the cost model below (scripts/dev_plan_time.py, SBM_RG_FORCE_PLAN; kernel ms, DOPRI45):
+#   cascade40, 2048 vectors   (4,16,1,10,5) 12.3   (3,20,1,14,4) 12.6   (6,10,1,7,8) 15.9   (2,27,1,20,3) 19.1
+#       model cost                           75                76                 96                  120
+#   cascade20, 4096 vectors   (3,20,2,7,1)   5.05  (3,20,1,7,2)   6.66  (6,10,1,4,4)  8.85
+#       model cost                           19                24                 36
 def _cost(elems, nch, rpl=1):
     # the kernel runs two wavefronts per SIMD when elements + state rows per lane <= REG_ELEMS (SBM_RG_MIN_WAVES)
     spill = 1.0 if elems + rpl <= REG_ELEMS else (1.6 if elems <= AGPR_ELEMS else 4.0 * elems / AGPR_ELEMS)
@@ -79,6 +84,12 @@ def plan(n, nk, max_lanes=64):
     more than 4 x 64 state variables."""
     if n < 2 or nk < 1 or n > MAX_ROWS_PER_LANE * max_lanes:
         return None
+    import os
+    forced = os.environ.get('SBM_RG_FORCE_PLAN')        # developer aid: "G,C,CPL,RPG,NCH" (timing one split against another)
+    if forced:
+        G, C, CPL, RPG, NCH = (int(v) for v in forced.split(','))
+        assert G * C <= max_lanes and G * RPG >= n and C * CPL * NCH >= nk and C * CPL * (NCH - 1) < nk, forced
+        return (G, C, CPL, RPG, NCH)
     rpl = -(-n // max_lanes)           # state rows per lane: rows lane, lane + 64, ...
     best = None
     for nch in range(1, 257):
