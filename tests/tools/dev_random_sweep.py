@@ -24,7 +24,7 @@ for k in range(n_models):
     t = np.linspace(0, 20.0, 1000); idx = np.array([0, 333, 999])
     Yr = oo.simulate(gm, P[1], t, use_c=True)[idx]; Sr = oo.calc_jacobian(gm, P[1], t, use_c=True)[idx]
     errs = []
-    for variant in ('per_wave', 'row_lane', 'row_group'):
+    for variant in ('per_wave', 'row_lane', 'row_group', 'small_batch'):
         S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant)
         assert not m.last_info['status'].any()
         errs.append(max(np.max(np.abs(Y[1] - Yr) / (1e-8 * np.abs(Yr) + 5e-9)), np.max(np.abs(S[1] - Sr) / (1e-8 * np.abs(Sr) + 5e-9))))
@@ -32,7 +32,7 @@ for k in range(n_models):
     errs.append(np.max(np.abs(S[1] - Sr) / (1e-8 * np.abs(Sr) + 5e-9)))
     Ys = m.simulate_batch(P, t[idx])
     errs.append(np.max(np.abs(Ys[1] - Yr) / (1e-8 * np.abs(Yr) + 5e-9)))
-    print("%-14s n=%2d k=%2d  err (tol units) per_wave %.2f row_lane %.2f row_group %.2f implicit %.2f state %.2f" % ((gm.spec.name, n, gm.n_sens) + tuple(errs)), flush=True)
+    print("%-14s n=%2d k=%2d  err (tol units) per_wave %.2f row_lane %.2f row_group %.2f small_batch %.2f implicit %.2f state %.2f" % ((gm.spec.name, n, gm.n_sens) + tuple(errs)), flush=True)
     worst = max(worst, max(errs))
 print("worst", worst)
 sys.exit(0 if worst <= 1.5 else 1)
