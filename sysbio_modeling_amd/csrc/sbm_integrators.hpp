@@ -333,8 +333,9 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
     const double target = t_out[io];
     while (!failed && t < target) {
       if (n_try >= max_steps) { out.status = SBM_MAX_STEPS; failed = true; break; }
-      if (early_exit && n_try >= 512 && (n_try & 255) == 0 && (o.t0 + t_span - t) > 4.0 * max_steps * h) {
-        out.status = SBM_MAX_STEPS; failed = true; break;
+      if (early_exit && n_try >= 512 && (n_try & 255) == 0) {
+        // (the end of the time span is read again here, in the cold path, rather than kept alive across the step loop)
+        if ((t_out[n_t - 1] - t) > 4.0 * max_steps * h) { out.status = SBM_MAX_STEPS; failed = true; break; }
       }
       ++n_try;
       // clip to land on the output time
