@@ -1,0 +1,58 @@
+"""The reference's own way of fitting, unchanged: SciPy's leastsq on Project.residuals with Project.calc_project_jacobian
+as Dfun (tests/test_Project.py:202-213 of the reference) -- one parameter vector per call, every call on the GPU.
+
+    python examples/leastsq_dropin.py
+
+8 experiments x 4 measured species x 16 time points = 512 residual rows, 68 parameters, 4 scale factors
+(BASELINE configs[3]); each Jacobian call integrates 8 x 820 coupled ODEs."""
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import scipy.optimize
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sysbio_modeling_amd import models_zoo
+from sysbio_modeling_amd.model import OdeModel
+from sysbio_modeling_amd.symbolic import zoo_model
+
+
+def main():
+    warnings.simplefilter('ignore')
+    gm = zoo_model('cascade20')
+    model = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order)
+    proj, theta_true = models_zoo.cascade_config4_project(model, reference_compat=False)
+    rng = np.random.default_rng(3)
+    x0 = theta_true + 0.1 * rng.standard_normal(theta_true.size)
+    # MINPACK's unconstrained steps in log-parameters can reach rates that make the system stiff for a trial or two;
+    # a step budget keeps such trials short (they come back as inf residuals, which leastsq rejects)
+    proj.integrator_options['max_steps'] = 20000
+    calls = {'f': 0, 'J': 0}
+
+    def f(x):
+        calls['f'] += 1
+        return proj.residuals(x)
+
+    def J(x):
+        calls['J'] += 1
+        return proj.calc_project_jacobian(x)
+    f(x0), J(x0)                                   # plugin load, first-call allocations
+    calls.update(f=0, J=0)
+    t0 = time.time()
+    x, cov, info, msg, ier = scipy.optimize.leastsq(f, x0, Dfun=J, full_output=True, maxfev=400)
+    dt = time.time() - t0
+    c0, c1 = 0.5 * np.sum(f(x0) ** 2), 0.5 * np.sum(info['fvec'] ** 2)
+    print("leastsq: %d residual calls + %d Jacobian calls in %.2f s (%.2f ms per call incl. MINPACK), ier = %d"
+          % (calls['f'], calls['J'], dt, 1e3 * dt / max(calls['f'] + calls['J'], 1), ier))
+    t0 = time.time()
+    for _ in range(20):
+        J(x)
+    print("at the fit: calc_project_jacobian %.2f ms per call" % (1e3 * (time.time() - t0) / 20))
+    print("cost 0.5 |r|^2: %.1f at the start -> %.3f at the fit (data generated with 5 %% noise: %.3f at the true parameters)"
+          % (c0, c1, 0.5 * np.sum(proj.residuals(theta_true) ** 2)))
+
+
+if __name__ == '__main__':
+    main()
