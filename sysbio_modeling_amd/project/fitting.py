@@ -28,7 +28,8 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     Failed integrations (inf cost) count as rejections.  Two safeguards keep wild trial points from
     stalling the whole batch (one launch waits for its slowest trajectory): every component of a step is
     clipped to ``max_step`` log-units, and trial integrations get a step budget
-    (``max_steps``, default 20000) -- a trial that exhausts it is simply rejected.
+    (``max_steps``, default -20000: a budget of 20000 attempts which a trajectory gives up at once when its current
+    step size could not finish within four budgets) -- a trial that exhausts it is simply rejected.
 
     With a handful of starts the chip is mostly empty: ``variant='small_batch'`` (an integrator override) lets the
     sensitivity kernel use its small-batch split while starts x experiments x chunks <= 1024.
@@ -37,7 +38,7 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     convergence (max_iter if never), converged (V,) bool, n_evaluations (total trial points integrated).
     """
     import torch
-    integrator_overrides.setdefault('max_steps', 20000)
+    integrator_overrides.setdefault('max_steps', -20000)     # negative: budget with early exit (include/sbm.h)
     if project.reference_compat and project.n_total_rows != project.n_project_residuals:
         raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
                          "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
