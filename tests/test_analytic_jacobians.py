@@ -19,10 +19,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _model(name):
-    return GeneratedModel(models_zoo.stiff_spec(12, name='stiff12')) if name == 'stiff12' else zoo_model(name)
+    if name == 'stiff12':
+        return GeneratedModel(models_zoo.stiff_spec(12, name='stiff12'))
+    if name == 'motif_fixed':       # conservation law + rate laws substituted, one parameter without a sensitivity column
+        from tests.test_gpu_user_models import MOTIF_TEXT
+        from sysbio_modeling_amd.symbolic import make_ode_model
+        return make_ode_model(MOTIF_TEXT, name='motif', fixed_params=['e_tot'])
+    return zoo_model(name)
 
 
-@pytest.mark.parametrize('name', ['simple', 'michaelis_menten', 'cascade20', 'stiff12'])
+@pytest.mark.parametrize('name', ['simple', 'michaelis_menten', 'cascade20', 'stiff12', 'motif_fixed'])
 def test_callbacks_equal_central_differences(name):
     gm = _model(name)
     n, k = gm.n_vars, gm.n_sens
