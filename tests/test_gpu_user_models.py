@@ -96,6 +96,10 @@ def test_more_sensitivity_columns_than_lanes():
         assert parity_err(Y[1], Yr[idx]) <= 1.0 and parity_err(S[1], Sr[idx]) <= 1.0, variant
         steps[variant] = m.last_info['n_steps'].copy()
     assert np.array_equal(steps['auto'], steps['row_group'])           # AUTO picks the chunked row-group kernel
+    # the single-vector call takes the small-batch split (eight chunks instead of three): same numbers to the tolerance
+    S_one = m.calc_jacobian(P[1], t[idx])
+    assert m.last_info['status'].tolist() == [0] and parity_err(S_one, Sr[idx]) <= 1.0
+    assert int(m.last_info['n_steps'][0]) != int(steps['auto'][1])
     S_rk = m.calc_jacobian_batch(P, t[idx], method='rk4', n_steps=8192)
     assert np.allclose(S_rk, S, rtol=1e-7, atol=1e-9)
     S_im = m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=8192, extrapolate=1,
