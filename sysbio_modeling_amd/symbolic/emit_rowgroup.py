@@ -112,6 +112,10 @@ def plan(n, nk, max_lanes=64):
     return sp[1:] + (nch,)
 
 
+# Calibration (scripts/dev_small_batch_time.py, SBM_RG_FORCE_PLAN_SMALL; GPU-busy ms of one Jacobian evaluation of the
+# configs[3] project, 8 trajectories of cascade20): 14 elements per lane (throughput split) 1.61, 7 elements 1.45,
+# 4 elements 1.01, 3 elements 1.00 / 0.97 / 0.96 with 5 / 8 / 10 chunks -- a plateau: the state evaluation and the step
+# control remain.  The small price per chunk below picks the fewest chunks on the plateau.
 def plan_latency(n, nk, max_lanes=64, max_chunks=16):
     """The split for SMALL batches (a serial optimiser evaluating one parameter vector at a time: the reference's
     leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)): the chip is empty, so extra wavefronts are
@@ -120,6 +124,12 @@ def plan_latency(n, nk, max_lanes=64, max_chunks=16):
     Returns (G, C, CPL, RPG, NCH) or None."""
     if n < 2 or nk < 1 or n > MAX_ROWS_PER_LANE * max_lanes:
         return None
+    import os
+    forced = os.environ.get('SBM_RG_FORCE_PLAN_SMALL')   # developer aid, as SBM_RG_FORCE_PLAN
+    if forced:
+        G, C, CPL, RPG, NCH = (int(v) for v in forced.split(','))
+        assert G * C <= max_lanes and G * RPG >= n and C * CPL * NCH >= nk and C * CPL * (NCH - 1) < nk, forced
+        return (G, C, CPL, RPG, NCH)
     rpl = -(-n // max_lanes)
     best = None
     for nch in range(1, max_chunks + 1):
