@@ -73,6 +73,57 @@ def test_model_text_with_laws_and_fixed_parameter(tmp_path):
     assert parity_err(S2[0], _odeint_ref(gm, P[0], t)[1][idx]) <= 1.0
 
 
+FORCED_TEXT = """
+#*! Parameters Start
+    k_in = p[0]
+    w = p[1]
+    d1 = p[2]
+    k2 = p[3]
+    d2 = p[4]
+#*! Parameters End
+#*! Variables Start
+    _a = y[0]
+    _b = y[1]
+#*! Variables End
+#*! Differential Equations Start
+    d__a = k_in * (1.0 + 0.5 * sin(w * t)) - d1 * _a
+    d__b = k2 * _a / (1.0 + _a) - d2 * _b * exp(-0.01 * t)
+#*! Differential Equations End
+"""
+
+
+def test_explicit_time_dependence():
+    """A non-autonomous right-hand side (periodic input, slowly decaying degradation): the callback contract carries t
+    (f(y, t, yout, p), the reference's fixtures ignore it), so every stage must evaluate the model at ITS time.  All
+    kernels, the implicit rule (midpoint time) and a start time other than zero against odeint."""
+    from sysbio_modeling_amd.symbolic import make_ode_model
+    from sysbio_modeling_amd.model import OdeModel
+    gm = make_ode_model(FORCED_TEXT, name='forced')
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='forced')
+    rng = np.random.default_rng(8)
+    P = np.array([1.0, 0.7, 0.2, 0.5, 0.3]) * np.exp(0.2 * rng.standard_normal((4, 5)))
+    t = np.linspace(0, 40.0, 1000)
+    idx = np.array([0, 250, 600, 999])
+    Yr, Sr = _odeint_ref(gm, P[2], t)
+    for variant in ('auto', 'per_wave', 'row_lane', 'row_group', 'small_batch'):
+        for method, kw in (('dopri45', {}), ('rk4', {'n_steps': 8192})):
+            S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant, method=method, **kw)
+            assert m.last_info['status'].max() == 0
+            assert parity_err(Y[2], Yr[idx]) <= 1.0 and parity_err(S[2], Sr[idx]) <= 1.0, (variant, method)
+    assert parity_err(m.simulate_batch(P, t[idx])[2], Yr[idx]) <= 1.0
+    S_im = m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=8192, extrapolate=1, rtol=1e-11, atol=1e-13)
+    assert parity_err(S_im[2], Sr[idx]) <= 1.0
+    S_c = m.calc_jacobian_batch(P, t[idx], method='implicit_controlled')
+    assert m.last_info['status'].max() == 0 and parity_err(S_c[2], Sr[idx]) <= 1.0
+    # t_sim[0] is the time of the initial condition (odeint semantics): start at t = 7.5 from a given state
+    t2 = np.linspace(7.5, 40.0, 400)
+    y0 = np.concatenate([[0.4, 0.9], np.zeros(10)])
+    from oracle import odeint_oracle as oo
+    Sr2, Yr2 = oo.calc_jacobian(gm, P[2], t2, init_conditions=y0, return_states=True)
+    S2, Y2 = m.calc_jacobian_batch(P[2:3], t2[[0, 150, 399]], init_conditions=y0, return_states=True)
+    assert parity_err(Y2[0], Yr2[[0, 150, 399]]) <= 1.0 and parity_err(S2[0], Sr2[[0, 150, 399]]) <= 1.0
+
+
 def test_more_sensitivity_columns_than_lanes():
     """35 species, 70 parameters: more columns than a wavefront has lanes.  The row-group kernel cuts them into
     chunks (one wavefront each, every chunk with its own copy of the state and its own step control); the
