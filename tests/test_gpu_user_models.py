@@ -124,6 +124,48 @@ def test_explicit_time_dependence():
     assert parity_err(Y2[0], Yr2[[0, 150, 399]]) <= 1.0 and parity_err(S2[0], Sr2[[0, 150, 399]]) <= 1.0
 
 
+HILL_TEXT = """
+#*! Parameters Start
+    vmax = p[0]
+    K = p[1]
+    d = p[2]
+    k2 = p[3]
+#*! Parameters End
+#*! Variables Start
+    _s = y[0]
+    _q = y[1]
+#*! Variables End
+#*! Rate Laws Start
+    hill = vmax * _q**4 / (K**4 + _q**4)
+#*! Rate Laws End
+#*! Differential Equations Start
+    d__s = k2 + hill - d * _s
+    d__q = k2 * sqrt(1.0 + _s) - d * _q * tanh(_q) - 0.1 * _q + log(1.0 + _s**2)
+#*! Differential Equations End
+"""
+
+
+def test_transcendental_rate_laws():
+    """Hill kinetics (fourth powers), sqrt, tanh and log in the rate laws: the device code of every kernel against
+    odeint on the generated Python callables (same expressions, printed for two languages)."""
+    from sysbio_modeling_amd.symbolic import make_ode_model
+    from sysbio_modeling_amd.model import OdeModel
+    gm = make_ode_model(HILL_TEXT, name='hill')
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='hill')
+    rng = np.random.default_rng(2)
+    P = np.array([1.0, 0.7, 0.2, 0.5]) * np.exp(0.25 * rng.standard_normal((5, 4)))
+    t = np.linspace(0, 30.0, 1000)
+    idx = np.array([0, 120, 500, 999])
+    Yr, Sr = _odeint_ref(gm, P[3], t)
+    for variant in ('auto', 'per_wave', 'row_lane', 'small_batch'):
+        S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant)
+        assert m.last_info['status'].max() == 0
+        assert parity_err(Y[3], Yr[idx]) <= 1.0 and parity_err(S[3], Sr[idx]) <= 1.0, variant
+    assert parity_err(m.simulate_batch(P, t[idx])[3], Yr[idx]) <= 1.0
+    S_c = m.calc_jacobian_batch(P, t[idx], method='implicit_controlled')
+    assert m.last_info['status'].max() == 0 and parity_err(S_c[3], Sr[idx]) <= 1.0
+
+
 def test_more_sensitivity_columns_than_lanes():
     """35 species, 70 parameters: more columns than a wavefront has lanes.  The row-group kernel cuts them into
     chunks (one wavefront each, every chunk with its own copy of the state and its own step control); the
