@@ -166,6 +166,49 @@ def test_transcendental_rate_laws():
     assert m.last_info['status'].max() == 0 and parity_err(S_c[3], Sr[idx]) <= 1.0
 
 
+ODD_TEXT = """
+#*! Parameters Start
+    k1 = p[0]
+    unused = p[1]
+    d1 = p[2]
+    k2 = p[3]
+#*! Parameters End
+#*! Variables Start
+    _a = y[0]
+    _b = y[1]
+    _c = y[2]
+#*! Variables End
+#*! Differential Equations Start
+    d__a = k1 - d1 * _a
+    d__b = k2 * _a - d1 * _b
+    d__c = 0.3 - 0.1 * _c
+#*! Differential Equations End
+"""
+
+
+def test_degenerate_structure():
+    """A parameter no equation uses (an all-zero sensitivity column, as the reference's expanded equations would
+    carry it), a state decoupled from everything with literal constants only, a parameter shared by two rows."""
+    from sysbio_modeling_amd.symbolic import make_ode_model
+    from sysbio_modeling_amd.model import OdeModel
+    gm = make_ode_model(ODD_TEXT, name='odd')
+    assert gm.n_vars == 3 and gm.n_sens == 4
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='odd')
+    P = np.array([[0.8, 5.0, 0.3, 0.6], [1.2, -1.0, 0.2, 0.9]])
+    t = np.linspace(0, 25.0, 1000)
+    idx = np.array([0, 200, 999])
+    for v in range(2):
+        Yr, Sr = _odeint_ref(gm, P[v], t)
+        for variant in ('auto', 'per_wave', 'row_lane', 'small_batch'):
+            S, Y = m.calc_jacobian_batch(P, t[idx], return_states=True, variant=variant)
+            assert m.last_info['status'].max() == 0
+            assert parity_err(Y[v], Yr[idx]) <= 1.0 and parity_err(S[v], Sr[idx]) <= 1.0, variant
+            Sv = S[v].reshape(len(idx), 3, 4)
+            assert np.all(Sv[:, :, 1] == 0.0) and np.all(Sv[:, 2, :] == 0.0)      # unused parameter; decoupled state
+    S_c = m.calc_jacobian_batch(P, t[idx], method='implicit_controlled')
+    assert m.last_info['status'].max() == 0 and parity_err(S_c[1], Sr[idx]) <= 1.0
+
+
 def test_more_sensitivity_columns_than_lanes():
     """35 species, 70 parameters: more columns than a wavefront has lanes.  The row-group kernel cuts them into
     chunks (one wavefront each, every chunk with its own copy of the state and its own step control); the
