@@ -27,8 +27,8 @@ def main():
     rng = np.random.default_rng(3)
     x0 = theta_true + 0.1 * rng.standard_normal(theta_true.size)
     # MINPACK's unconstrained steps in log-parameters can reach rates that make the system stiff for a trial or two;
-    # a step budget keeps such trials short (they come back as inf residuals, which leastsq rejects)
-    proj.integrator_options['max_steps'] = 20000
+    # the default step budget (50000 attempts, given up early when hopeless) keeps such trials short: they come back as
+    # inf residuals, which leastsq rejects
     calls = {'f': 0, 'J': 0}
 
     def f(x):
@@ -52,6 +52,18 @@ def main():
     print("at the fit: calc_project_jacobian %.2f ms per call" % (1e3 * (time.time() - t0) / 20))
     print("cost 0.5 |r|^2: %.1f at the start -> %.3f at the fit (data generated with 5 %% noise: %.3f at the true parameters)"
           % (c0, c1, 0.5 * np.sum(proj.residuals(theta_true) ** 2)))
+    # A start further away: some of MINPACK's trial points are stiff.  With a plain step budget they come back as inf
+    # residuals; method='auto' integrates them with the implicit rule instead -- what LSODA does for the reference.
+    x0_far = theta_true + 0.3 * rng.standard_normal(theta_true.size)
+    for label, opts in (("default (explicit, step budget)", dict(method='dopri45')),
+                        ("method='auto'", dict(method='auto'))):
+        proj.integrator_options.update(opts)
+        calls.update(f=0, J=0)
+        t0 = time.time()
+        x, cov, info, msg, ier = scipy.optimize.leastsq(f, x0_far, Dfun=J, full_output=True, maxfev=400)
+        dt = time.time() - t0
+        print("far start, %-31s %3d + %3d calls in %5.2f s, cost %.3f" % (label + ':', calls['f'], calls['J'], dt,
+                                                                           0.5 * np.sum(info['fvec'] ** 2)))
 
 
 if __name__ == '__main__':

@@ -84,7 +84,7 @@ class Project(object):
         self._rows = None
         self._last = {}
         self.integrator_options = dict(getattr(model, 'integrator_options', {}) or
-                                       dict(method='dopri45', rtol=1e-9, atol=1e-12, max_steps=0))
+                                       dict(method='dopri45', rtol=1e-9, atol=1e-12, max_steps=-50000))
         self.add_experiment(experiments)
         self._project_param_vector = np.zeros((self.n_project_params,))
 
@@ -625,7 +625,7 @@ class Project(object):
             out, st, steps, _ = controlled(np.arange(V))
             stiff = np.ones(V, dtype=bool)
         else:
-            budget = int(o.get('max_steps') or 0) or 50000
+            budget = abs(int(o.get('max_steps') or 0)) or 50000
             out, st, steps, stiff = _control.with_stiff_fallback(
                 lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=-budget,
                                                   rtol=rtol, atol=atol, extrapolate=0, **keep)),
