@@ -105,6 +105,10 @@ def test_odemodel_signature_checks(zoo):
     m = OdeModel(gm.model, gm.sens_model, 1, gm.param_order, use_jit=False)
     assert m.n_vars == 1 and m.get_n_vars() == 1 and m.param_order == ['k_deg', 'k_synt']
     assert m.use_jac is True and m._jit_enabled is False and m.model_name == 'Model'
+    # defaults: the explicit pair at the tolerance that keeps parity with LSODA, a step budget with early exit
+    assert m.integrator_options == dict(method='dopri45', rtol=1e-9, atol=1e-12, max_steps=-50000)
+    o = _lib.make_opts(**m.integrator_options)
+    assert (o.method, o.max_steps, o.variant) == (_lib.SBM_DOPRI45, -50000, 0)
 
 
 def test_make_opts():
