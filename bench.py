@@ -10,10 +10,17 @@ Jacobian assembly of a one-experiment Project on top (64 rows x 40 parameters pe
 value = accepted integrator steps of all trajectories of all ranks / wall time.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N ...          spawns N ranks itself (torch.distributed.run, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: the ensemble is sharded by vector index (weak scaling: 4096 vectors per GPU, no
 data-path collective); RCCL carries only the all-gather of the per-vector residual norms.
+
+At N = 1 the line also carries, under "configs", BASELINE.json's other configurations -- configs[1]
+(state only), configs[3] (8-experiment Project), configs[4] (stiff 50-state model) -- each with its own
+`roofline` and `cpu_baseline` objects, "fit" (end-to-end multi-start fitting against the reference's
+serial leastsq pattern) and "dense" (the MFMA question).  `--only NAME` runs one of them alone (what the
+rocprofv3 passes of scripts/profile_gpu.sh use).  The side workloads live in bench_configs.py.
 """
 import argparse
 import ctypes
@@ -29,9 +36,12 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 1024                # 256 CUs x 4 SIMDs
+MAX_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md: max clock
 N_AUG = 820                  # 20 + 20*40 coupled ODEs
 BYTES_PER_STEP = 2 * 8 * N_AUG   # read + write the augmented state once per step
 V_PER_GPU = 4096
+COUNTERS = os.path.join(REPO, 'profiles', 'kernel_counters.json')   # written by scripts/summarize_profile.py
 
 
 def build_workload(model, gm, n_vectors, rank):
@@ -67,49 +77,67 @@ def build_workload(model, gm, n_vectors, rank):
     return proj, np.ascontiguousarray(theta[:, order]), grid[idx]
 
 
-def cpu_baseline(gm, theta_rows, budget_s=12.0, max_vectors=4096):
-    """The oracle (SciPy odeint restatement of OdeModel.calc_jacobian, compiled C RHS standing in
-    for the reference's numba) timed on ONE host core over a bounded sample of the same ensemble."""
+# ---------------------------------------------------------------------------
+# CPU legs: the oracle (SciPy odeint restatement of the reference, compiled C RHS standing in for its numba)
+# timed on the GPU box's host cores over BOUNDED samples of the same workloads
+# ---------------------------------------------------------------------------
+def cpu_baseline(gm, theta_rows, budget_s=12.0, max_vectors=4096, sens=True, t_end=100.0):
+    """One host core; the reference's exact odeint call per vector on its 1000-point grid."""
     from oracle import odeint_oracle as oo
-    grid = np.linspace(0, 100.0, 1000)
+    grid = np.linspace(0, t_end, 1000)
     steps, n, t0 = 0, 0, time.perf_counter()
     gm.c_library()
     for row in theta_rows[:max_vectors]:
-        _, info = oo.calc_jacobian(gm, np.exp(row), grid, use_c=True, full_output=True)
+        if sens:
+            _, info = oo.calc_jacobian(gm, np.exp(row), grid, use_c=True, full_output=True)
+        else:
+            _, info = oo.simulate(gm, np.exp(row), grid, use_c=True, full_output=True)
         steps += int(info['nst'][-1])
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "ODE-steps/s", "cores": 1, "kind": "port",
-            "sample": "first %d vectors of the ensemble, state+sensitivity system (820 ODEs), "
-                      "scipy.integrate.odeint rtol=atol=1e-10 on the reference's 1000-point grid, "
-                      "compiled C RHS; %.1f s, %d LSODA steps" % (n, dt, steps),
+            "sample": "first %d vectors of the ensemble, %s, scipy.integrate.odeint rtol=atol=1e-10 on the "
+                      "reference's 1000-point grid, compiled C RHS; %.1f s, %d LSODA steps"
+                      % (n, "state+sensitivity system (%d ODEs)" % (gm.n_vars * (1 + gm.n_sens)) if sens
+                         else "state system (%d ODEs)" % gm.n_vars, dt, steps),
             "ms_per_vector": 1e3 * dt / max(n, 1)}
 
 
-def residual_parity(gm, proj, theta_rows, res_gpu, jac_gpu, n_check=3):
-    """BASELINE.json's second figure: residual (and Jacobian) error of the timed GPU pass against the
-    SciPy restatement of the reference's Project on the same inputs, for the first few vectors.  Reported
-    in the units of the parity tolerance |gpu - ref| <= 1e-8 |ref| + 5e-9 of the underlying trajectories;
-    residual rows are trajectories divided by sigma ~ 0.06, so their floor scales by 1 / sigma;
-    ``residual_rel_err`` is |r_gpu - r_scipy|_2 / |r_scipy|_2, the worst of the checked vectors."""
+def project_oracle_of(gm, proj):
     from oracle.project_oracle import ProjectOracle
-    po = ProjectOracle(gm, list(proj.experiments), proj._model_parameter_settings,
-                       {k: v for k, v in proj._measurement_to_model_map_raw.items()},
-                       sf_groups=[g if len(g) > 1 else g[0] for g in proj._loss_function.groups])
-    sig = proj.descriptor_arrays()['row_sigma']
-    worst_r = worst_rel = worst_j = 0.0
-    for v in range(n_check):
-        rr = po.residuals(theta_rows[v])
+    return ProjectOracle(gm, list(proj.experiments), proj._model_parameter_settings,
+                         {k: v for k, v in proj._measurement_to_model_map_raw.items()},
+                         sf_groups=[g if len(g) > 1 else g[0] for g in proj._loss_function.groups])
+
+
+def residual_parity(gm, proj, theta_rows, res_gpu, jac_gpu, picks):
+    """BASELINE.json's second figure: residual (and Jacobian) error of the timed GPU pass against the SciPy
+    restatement of the reference's Project on the same inputs, for ``picks`` (indices spread over the batch).
+    Tolerance (oracle/tolerances.py): the sampled trajectories agree with the reference's LSODA to
+    |gpu - ref| <= 1e-8 |ref| + 5e-9 (the absolute term is LSODA's own noise at atol = 1e-10); residual and
+    Jacobian rows get the first-order propagation of exactly that through the reference's formulas."""
+    from oracle import tolerances as tol
+    po = project_oracle_of(gm, proj)
+    a = proj.descriptor_arrays()
+    worst_r = worst_rel = worst_j = worst_n = 0.0
+    for v in picks:
+        rr, sims, B = po.residuals(theta_rows[v], return_parts=True)
+        Jm = po.model_jacobian(theta_rows[v])
         Jr = po.calc_project_jacobian(theta_rows[v])
-        d = np.abs(res_gpu[v] - rr)
-        worst_r = max(worst_r, float(np.max(d / (1e-8 * np.abs(rr) + 5e-9 / sig))))
+        tau_s, tau_Jm = tol.lsoda_taus(a, theta_rows[v], sims, Jm)
+        t = tol.project_tolerances(a, sims, B, tau_s, Jm, tau_Jm)
+        worst_r = max(worst_r, tol.tol_ratio(res_gpu[v], rr, t['residuals']))
         worst_rel = max(worst_rel, float(np.linalg.norm(res_gpu[v] - rr) / np.linalg.norm(rr)))
-        worst_j = max(worst_j, float(np.max(np.abs(jac_gpu[v] - Jr) / (1e-8 * np.abs(Jr) + 1e-8 * np.abs(Jr).max()))))
-    return {"vectors_checked": n_check, "residual_err_in_tolerance_units": worst_r,
+        worst_j = max(worst_j, tol.tol_ratio(jac_gpu[v], Jr, t['jacobian']))
+        worst_n = max(worst_n, abs(float(np.sum(res_gpu[v] ** 2)) / float(np.sum(rr ** 2)) - 1.0))
+    return {"vectors_checked": len(picks), "residual_err_in_tolerance_units": worst_r,
             "residual_rel_err": worst_rel, "jacobian_err_in_tolerance_units": worst_j,
-            "tolerance": "|gpu - scipy| <= 1e-8 |scipy| + 5e-9 / sigma (residuals); 1e-8 (|J| + max|J|) (Jacobian)",
+            "norm_rel_err": worst_n,
+            "tolerance": "trajectories |gpu - scipy| <= 1e-8 |scipy| + 5e-9 (LSODA's own absolute noise at atol "
+                         "1e-10), propagated to first order through B, (B s - d) / sigma and B J + s dB/dtheta "
+                         "(oracle/tolerances.py::project_tolerances); <= 1 passes",
             "reference": "ProjectOracle: scipy.integrate.odeint rtol=atol=1e-10, reference_compat Jacobian"}
 
 
@@ -151,6 +179,90 @@ def cpu_baseline_all_cores(theta_rows, budget_s=10.0):
                                                        time.perf_counter() - t0)}
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1) as a CHILD process and hand its stdout / exit code through.  Nothing in this
+    process initialises a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------
+# rooflines
+# ---------------------------------------------------------------------------
+def _counters():
+    try:
+        with open(COUNTERS) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def hbm_roofline(kernel, key, k_ms, k_steps, bytes_per_step, note):
+    """Algorithmic-byte roofline of SURVEY.md section 8(d): bytes_per_step x accepted steps of one launch / the
+    launch's duration (HIP events on the kernel's stream), against the HBM peak.  `traffic` = HBM bytes per launch
+    from the PMC passes of this round's profile (profiles/kernel_counters.json: (2 FETCH_SIZE + WRITE_SIZE) KiB,
+    separate passes, the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md), null when no profile is committed."""
+    c = _counters().get(key, {})
+    achieved = k_steps * bytes_per_step / (k_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": c.get('hbm_bytes_per_launch'),
+            "traffic_source": c.get('source'),
+            "kernel": kernel, "kernel_ms": k_ms, "steps_per_launch": k_steps,
+            "algorithmic_bytes_per_step": bytes_per_step, "kernel_steps_per_s": k_steps / (k_ms * 1e-3), "note": note}
+
+
+def valu_roofline(key, k_ms, k_steps):
+    """The resource that actually binds the register-resident integrators: VALU instruction issue.
+    achieved = (VALU wave-instructions per accepted step, PMC: SQ_INSTS_VALU / steps) x steps per second;
+    peak = 1024 SIMDs x 2.4 GHz / (cycles one such instruction holds its SIMD's issue port, PMC:
+    4 SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU -- the counter ticks in quad-cycles).  Both PMC figures come from the
+    committed profile of the same kernel; the rate is measured live."""
+    c = _counters().get(key, {})
+    if not c.get('valu_insts_per_step') or not c.get('cycles_per_valu_inst'):
+        return None
+    achieved = c['valu_insts_per_step'] * k_steps / (k_ms * 1e-3)
+    peak = N_SIMD * MAX_CLOCK_HZ / c['cycles_per_valu_inst']
+    return {"bound": "valu_issue", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+            "frac": achieved / peak, "valu_insts_per_step": c['valu_insts_per_step'],
+            "cycles_per_valu_inst": c['cycles_per_valu_inst'],
+            "valu_busy_fraction_pmc": c.get('valu_busy_fraction'), "source": c.get('source'),
+            "note": "peak at the 2.4 GHz maximum clock; the chip holds less under load, so frac understates how "
+                    "close to the issue limit the kernel runs (valu_busy_fraction_pmc is the direct reading)"}
+
+
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """The JSON line must be the only thing on stdout, but ODEPACK (the CPU legs' LSODA) writes its warnings to
+    Fortran unit 6 = the C-level stdout, buffered until exit.  So: keep a private duplicate of the real stdout for
+    the JSON line and point file descriptor 1 at stderr for everything else, for the life of the process."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -160,26 +272,39 @@ def main():
     ap.add_argument('--method', default='dopri45', choices=['dopri45', 'rk4'])
     ap.add_argument('--rk4-steps', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help="headline only: no other configs, no variants")
+    ap.add_argument('--only', default=None, help="run one workload's GPU part alone, --steps times (profiling aid; "
+                    "headline, configs1, configs3, configs4, fit, dense); no JSON contract")
     ap.add_argument('--cpu-baseline-only', action='store_true', help="time the CPU oracle and exit (no GPU needed)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher.  This process never imports torch or
+        # touches a GPU; the N ranks (one per device, backend nccl = RCCL) are children and rank 0 prints the line.
+        sys.exit(self_launch(args.gpus))
+    protect_stdout()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d started inside a world of %d ranks: launch with "
+                         "torch.distributed.run --nproc-per-node %d (or plain `python bench.py --gpus %d`, which "
+                         "spawns the ranks itself)" % (args.gpus, world, args.gpus, args.gpus))
+    with_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.only is None
     cpu_all = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if with_cpu:
         from sysbio_modeling_amd import models_zoo as _mz
         cpu_all = cpu_baseline_all_cores(_mz.cascade_ensemble(args.vectors)[0])
     if args.cpu_baseline_only:
         from sysbio_modeling_amd.symbolic import zoo_model as _zm
         from sysbio_modeling_amd import models_zoo as _mz
-        print(json.dumps({"cpu_baseline": cpu_baseline(_zm('cascade20'), _mz.cascade_ensemble(args.vectors)[0]),
-                          "cpu_baseline_all_cores": cpu_all}))
+        emit({"cpu_baseline": cpu_baseline(_zm('cascade20'), _mz.cascade_ensemble(args.vectors)[0]),
+              "cpu_baseline_all_cores": cpu_all})
         return
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
+    n_dev = torch.cuda.device_count()      # (counting devices does not initialise the GPU)
+    if n_dev == 0 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # rehearsal knob (not used by the driver): SBM_BENCH_REHEARSAL=1 runs every rank on GPU 0 over gloo, so
     # that the multi-rank code path can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
@@ -187,6 +312,9 @@ def main():
     if rehearsal:
         local_rank = 0
         os.environ['LOCAL_RANK'] = '0'
+    if local_rank >= n_dev:
+        raise SystemExit("bench.py --gpus %d: rank %d has no device (%d visible); one process per GPU"
+                         % (args.gpus, rank, n_dev))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -194,14 +322,18 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from sysbio_modeling_amd import _lib
     from sysbio_modeling_amd.symbolic import zoo_model
     from sysbio_modeling_amd.model import OdeModel
+    import bench_configs as bc
     gm = zoo_model('cascade20')
     model = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, use_jit=False)
     model.enable_jit(_lib.Context(local_rank))
+    if args.only not in (None, 'headline'):
+        out = bc.RUNNERS[args.only](model, gm, dev, reps=max(1, args.steps), cpu=False)
+        emit({args.only: out})
+        return
     V = args.vectors
     proj, theta, t_meas = build_workload(model, gm, V, rank)
     lib = _lib.load_library()
@@ -248,10 +380,49 @@ def main():
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        per_rank = torch.empty((world,), dtype=f64, device=dev)
+        dist.all_gather_into_tensor(per_rank, stats[:1].contiguous())
+        per_rank_ms = [1e3 * float(x) / args.steps for x in per_rank.cpu()]
         dt, total_steps_per_pass, n_bad = float(mx[0]), float(sm[1]), int(sm[2])
+        world_seen = dist.get_world_size()
+        backend = dist.get_backend()
+        norms_ok = bool(torch.equal(gathered[rank * V:(rank + 1) * V], out['norms']))
     else:
         total_steps_per_pass = float(steps_per_pass)
+        per_rank_ms, world_seen, backend, norms_ok = [1e3 * dt / args.steps], 1, None, True
     value = total_steps_per_pass * args.steps / dt
+    if args.only == 'headline':
+        emit({"headline": {"ms_per_step": 1e3 * dt / args.steps, "value": value,
+                           "steps_per_pass": total_steps_per_pass}})
+        return
+
+    # ---- SURVEY.md section 8(d)'s host-inclusive figure: P upload and download of the sampled rows / norms ----
+    host_incl = None
+    if world == 1:
+        th_pin = torch.from_numpy(theta).pin_memory()
+        res_pin = torch.empty((V, R), dtype=f64).pin_memory()
+        nrm_pin = torch.empty((V,), dtype=f64).pin_memory()
+        J_pin = torch.empty((V, R, q), dtype=f64).pin_memory()
+
+        def host_step(with_J):
+            th.copy_(th_pin, non_blocking=True)
+            step()
+            res_pin.copy_(out['res'], non_blocking=True)
+            nrm_pin.copy_(out['norms'], non_blocking=True)
+            if with_J:
+                J_pin.copy_(out['J'], non_blocking=True)
+        host_incl = {}
+        for with_J, key in ((False, "value_host_inclusive"), (True, "value_host_inclusive_with_jacobian_download")):
+            host_step(with_J)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                host_step(with_J)
+            torch.cuda.synchronize(dev)
+            host_incl[key] = total_steps_per_pass * args.steps / (time.perf_counter() - t1)
+        host_incl["note"] = ("SURVEY.md section 8(d): per pass, theta (V x 40 f64) uploaded from pinned host memory "
+                             "and residual rows + norms (V x 65 f64) downloaded; the second figure also downloads "
+                             "the Jacobian (V x 64 x 40 f64 = 84 MB per pass); never reported as `value`")
 
     # ---- roofline of the dominant kernel: the sensitivity integrator alone, HIP events on its stream ----
     dm = model.device_model
@@ -271,131 +442,13 @@ def main():
     torch.cuda.synchronize(dev)
     k_ms = e0.elapsed_time(e1) / args.steps
     k_steps = int(ns_k.sum().item())
-    achieved = k_steps * BYTES_PER_STEP / (k_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(tpath):
-        with open(tpath) as fh:
-            traffic = json.load(fh).get(args.method, {}).get('hbm_bytes_per_launch')
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "sbm_sens_rowgroup_kernel<cascade20,%s>" % args.method, "kernel_ms": k_ms,
-                "steps_per_launch": k_steps, "algorithmic_bytes_per_step": BYTES_PER_STEP,
-                "kernel_steps_per_s": k_steps / (k_ms * 1e-3),
-                "note": "algorithmic bytes (2*8*820 B per accepted step) / kernel time; the kernel keeps the "
-                        "state in VGPRs, so real HBM traffic ('traffic', PMC) is far below this figure and the "
-                        "binding resource is VALU issue (profiles/r01e/pmc_summary.json)"}
-
-    extras = {}
-    if not args.no_extras and rank == 0 and world == 1:   # single-GPU micro-benchmarks
-        def time_kernel(kind, o, reps=3):
-            for _ in range(1):
-                (dm.sens_dev(theta_p, tg, None, o, Yk, Sk, None, ns_k, None) if kind == 'sens'
-                 else dm.simulate_dev(theta_p, tg, None, o, Yk, None, ns_k, None))
-            torch.cuda.synchronize(dev)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(reps):
-                (dm.sens_dev(theta_p, tg, None, o, Yk, Sk, None, ns_k, None) if kind == 'sens'
-                 else dm.simulate_dev(theta_p, tg, None, o, Yk, None, ns_k, None))
-            b.record()
-            torch.cuda.synchronize(dev)
-            ms = a.elapsed_time(b) / reps
-            st = int(ns_k.sum().item())
-            return {"ms": ms, "steps": st, "steps_per_s": st / (ms * 1e-3)}
-        rk = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0)
-        dp = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
-        dp_rl = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant='row_lane')
-        rk_rl = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0, variant='row_lane')
-        dp_pw = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant='per_wave')
-        rk_pw = _lib.make_opts('rk4', n_steps=args.rk4_steps, t_end=100.0, variant='per_wave')
-        extras = {"sens_rk4_fixed_%d" % args.rk4_steps: time_kernel('sens', rk),
-                  "sens_dopri45": time_kernel('sens', dp),
-                  "sens_dopri45_row_lane_variant": time_kernel('sens', dp_rl),
-                  "sens_rk4_fixed_%d_row_lane_variant" % args.rk4_steps: time_kernel('sens', rk_rl),
-                  "sens_dopri45_per_wave_variant": time_kernel('sens', dp_pw),
-                  "sens_rk4_fixed_%d_per_wave_variant" % args.rk4_steps: time_kernel('sens', rk_pw),
-                  "state_only_dopri45_configs1": time_kernel('state', dp),
-                  "state_only_rk4_fixed_%d" % args.rk4_steps: time_kernel('state', rk)}
-        # BASELINE configs[3]: 8 experiment settings x 1024 vectors, residual + Jacobian assembly
-        import warnings
-        from sysbio_modeling_amd import models_zoo
-        with warnings.catch_warnings():
-            warnings.simplefilter('ignore')
-            p4, th4 = models_zoo.cascade_config4_project(model)
-        t4 = torch.from_numpy(models_zoo.config4_ensemble(th4, 1024)).to(dev)
-        p4.evaluate_batch(t4, jacobian=True, want=('jacobian',))
-        torch.cuda.synchronize(dev)
-        a4, b4 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a4.record()
-        for _ in range(3):
-            o4 = p4.evaluate_batch(t4, jacobian=True, want=('jacobian',))
-        b4.record()
-        torch.cuda.synchronize(dev)
-        ms4 = a4.elapsed_time(b4) / 3
-        st4 = int(o4['n_steps'].sum().item())
-        extras["configs3_project_8exp_x_1024vec"] = {"ms": ms4, "steps": st4, "steps_per_s": st4 / (ms4 * 1e-3),
-                                                     "rows": 512, "params": 68,
-                                                     "failed_vectors": int((o4['status'] != 0).sum().item())}
-
-        # BASELINE configs[4]: stiff 50-state cascade, 2550 coupled ODEs, implicit midpoint, 4096 vectors.
-        # One launch per Richardson level; the parity setting of tests/test_gpu_implicit.py is 4096 + 8192
-        # steps (extrapolate=1), timed here: the 2048-step launch, whose cost scales linearly.
-        gm5 = zoo_model('stiff50')
-        m5 = OdeModel(gm5.model, gm5.sens_model, gm5.n_vars, gm5.param_order, use_jit=False)
-        P5 = torch.from_numpy(models_zoo.stiff_ensemble(4096)[1]).to(dev)
-        t5 = torch.tensor([5.0, models_zoo.STIFF_T_END], dtype=f64, device=dev)
-        Y5 = torch.empty((4096, 2, 50), dtype=f64, device=dev)
-        S5 = torch.empty((4096, 2, 50, 50), dtype=f64, device=dev)
-        st5 = torch.empty((4096,), dtype=i32, device=dev)
-        ns5 = torch.empty((4096,), dtype=i32, device=dev)
-        nw5 = torch.empty((4096,), dtype=i32, device=dev)
-        o5 = _lib.make_opts('implicit_midpoint', rtol=1e-10, atol=1e-12, n_steps=2048, t_end=models_zoo.STIFF_T_END)
-        m5.device_model.sens_dev(P5, t5, None, o5, Y5, S5, st5, ns5, nw5)
-        torch.cuda.synchronize(dev)
-        a5, b5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a5.record()
-        m5.device_model.sens_dev(P5, t5, None, o5, Y5, S5, st5, ns5, nw5)
-        b5.record()
-        torch.cuda.synchronize(dev)
-        ms5 = a5.elapsed_time(b5)
-        n5 = int(ns5.sum().item())
-        extras["configs4_stiff50_implicit_midpoint_2048_steps"] = {
-            "ms": ms5, "steps": n5, "steps_per_s": n5 / (ms5 * 1e-3), "n_equations": 2550,
-            "newton_iterations_per_step": 1.0 + float(nw5.sum().item()) / n5,
-            "algorithmic_GBps": n5 / (ms5 * 1e-3) * 2 * 8 * 2550 / 1e9,
-            "failed_vectors": int((st5 != 0).sum().item())}
-
-        # A model beyond one row / one column per lane: 70 states, 140 parameters, 9870 coupled ODEs per trajectory
-        # (two state rows per lane, sensitivity columns in 14 chunks of 10, one wavefront each).  The plugin is
-        # built here (hipcc, ~15 s); a failure to build must not cost the headline line.
-        try:
-            from sysbio_modeling_amd.symbolic import GeneratedModel
-            gm7 = GeneratedModel(models_zoo.cascade_spec(70, name='cascade70'))
-            m7 = OdeModel(gm7.model, gm7.sens_model, gm7.n_vars, gm7.param_order, use_jit=False)
-            V7 = 1024
-            P7 = torch.from_numpy(models_zoo.cascade_ensemble(V7, n=70, spread=0.3)[1]).to(dev)
-            t7 = torch.tensor([50.0, 100.0], dtype=f64, device=dev)
-            Y7 = torch.empty((V7, 2, 70), dtype=f64, device=dev)
-            S7 = torch.empty((V7, 2, 70, 140), dtype=f64, device=dev)
-            st7 = torch.empty((V7,), dtype=i32, device=dev)
-            ns7 = torch.empty((V7,), dtype=i32, device=dev)
-            o7 = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
-            m7.device_model.sens_dev(P7, t7, None, o7, Y7, S7, st7, ns7, None)
-            torch.cuda.synchronize(dev)
-            a7, b7 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a7.record()
-            m7.device_model.sens_dev(P7, t7, None, o7, Y7, S7, st7, ns7, None)
-            b7.record()
-            torch.cuda.synchronize(dev)
-            ms7 = a7.elapsed_time(b7)
-            n7 = int(ns7.sum().item())
-            extras["large_model_cascade70_dopri45"] = {
-                "ms": ms7, "steps": n7, "steps_per_s": n7 / (ms7 * 1e-3), "n_equations": 70 + 70 * 140, "vectors": V7,
-                "algorithmic_GBps": n7 / (ms7 * 1e-3) * 2 * 8 * (70 + 70 * 140) / 1e9,
-                "failed_vectors": int((st7 != 0).sum().item())}
-        except Exception as e:   # noqa: BLE001
-            extras["large_model_cascade70_dopri45"] = {"error": repr(e)[:200]}
+    kkey = 'sens_rowgroup_cascade20_%s' % args.method
+    roofline = hbm_roofline("sbm_sens_rowgroup_kernel<cascade20,%s>" % args.method, kkey, k_ms, k_steps,
+                            BYTES_PER_STEP,
+                            "algorithmic bytes (2*8*820 B per accepted step) / kernel time; the kernel keeps the "
+                            "state in VGPRs, so real HBM traffic ('traffic', PMC) is far below this figure and the "
+                            "binding resource is VALU issue: see roofline_valu_issue")
+    roofline_valu = valu_roofline(kkey, k_ms, k_steps)
 
     result = {
         "metric": "ensemble ODE-steps/sec (20-state model + fwd sens)",
@@ -411,20 +464,39 @@ def main():
                    "vectors_per_gpu": V, "n_equations": N_AUG, "integrator": args.method,
                    "accepted_steps_per_pass": total_steps_per_pass, "failed_vectors": n_bad},
         "roofline": roofline,
+        "ranks": {"world_size_seen": world_seen, "backend": backend, "ms_per_step_by_rank": per_rank_ms,
+                  "gathered_norms_match_local_block": norms_ok},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if roofline_valu:
+        result["roofline_valu_issue"] = roofline_valu
+    if host_incl:
+        result["host_inclusive"] = host_incl
+    if with_cpu:
         result["cpu_baseline"] = cpu_baseline(gm, theta)
         result["cpu_baseline_all_cores"] = cpu_all
+        picks = [int(x) for x in np.linspace(0, V - 1, 64).astype(int)]
         result["cpu_baseline"]["parity_of_timed_pass"] = residual_parity(
-            gm, proj, theta, out['res'][:3].cpu().numpy(), out['J'][:3].cpu().numpy())
+            gm, proj, theta, out['res'].cpu().numpy(), out['J'].cpu().numpy(), picks)
     elif rank == 0:
         result["cpu_baseline"] = None
-    if extras:
-        result["extras"] = extras
+
+    if not args.no_extras and rank == 0 and world == 1:
+        # BASELINE.json's other configurations, each with its own roofline and CPU leg; then kernel variants
+        cfgs = {}
+        for name in bc.ORDER:
+            try:
+                cfgs[name] = bc.RUNNERS[name](model, gm, dev, reps=3, cpu=not args.no_cpu_baseline)
+            except Exception as e:   # noqa: BLE001 -- a failing side config must not cost the headline line
+                cfgs[name] = {"error": repr(e)[:300]}
+        result["configs"] = cfgs
+        try:
+            result["extras"] = bc.variant_extras(model, dev, theta_p, tg, args.rk4_steps)
+        except Exception as e:   # noqa: BLE001
+            result["extras"] = {"error": repr(e)[:300]}
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if world > 1:
-        dist.barrier()   # rank 0 arrives late (extras run after the timed region)
+        dist.barrier()   # rank 0 arrives late
         dist.destroy_process_group()
 
 

@@ -1,0 +1,351 @@
+"""Side workloads of bench.py: BASELINE.json's configs[1], [3], [4], the end-to-end fitting figure and the kernel
+variants.  Every runner returns one dict with the GPU timing (HIP events on the context's stream = torch's
+current stream), a `roofline` object for its dominant kernel, and -- with ``cpu=True`` -- a `cpu_baseline` object:
+the oracle (SciPy restatement of the reference) timed on one host core over a bounded sample of the same workload.
+
+Runner signature: run(model, gm, dev, reps, cpu) with (model, gm) the cascade20 OdeModel / GeneratedModel.
+"""
+import time
+import warnings
+
+import numpy as np
+
+import bench as B
+
+
+def _events(torch, dev, fn, reps, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize(dev)
+    return a.elapsed_time(b) / reps
+
+
+# ---------------------------------------------------------------------------
+# configs[1]: 20-state model, 4096 vectors, no sensitivities
+# ---------------------------------------------------------------------------
+def run_configs1(model, gm, dev, reps=3, cpu=True):
+    import torch
+    from sysbio_modeling_amd import _lib, models_zoo
+    V = 4096
+    theta, P = models_zoo.cascade_ensemble(V)
+    dm = model.device_model
+    Pd = torch.from_numpy(P).to(dev)
+    grid = np.linspace(0, models_zoo.CASCADE_T_END, 1000)
+    tg = torch.from_numpy(np.concatenate([[0.0], grid[np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)]])).to(dev)
+    Y = torch.empty((V, len(tg), 20), dtype=torch.float64, device=dev)
+    ns = torch.empty((V,), dtype=torch.int32, device=dev)
+    st = torch.empty((V,), dtype=torch.int32, device=dev)
+    out = {"workload": "configs[1]: cascade20, 4096 parameter vectors, state only (20 ODEs), 16 output times"}
+    for label, o, bytes_note in (
+            ('dopri45', _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12), 'DOPRI45 rtol=1e-9 atol=1e-12'),
+            ('rk4_fixed_4096', _lib.make_opts('rk4', n_steps=4096, t_end=100.0), 'RK4, 4096 fixed steps')):
+        ms = _events(torch, dev, lambda: dm.simulate_dev(Pd, tg, None, o, Y, st, ns, None), reps)
+        steps = int(ns.sum().item())
+        r = {"ms": ms, "steps": steps, "value": steps / (ms * 1e-3), "unit": "ODE-steps/s", "integrator": bytes_note,
+             "failed_vectors": int((st != 0).sum().item()),
+             "roofline": B.hbm_roofline("sbm_state_packed_kernel<cascade20,%s>" % label, 'state_packed_cascade20_' + label,
+                                        ms, steps, 2 * 8 * 20,
+                                        "SURVEY.md section 8(d): 320 B per accepted step (read + write 20 doubles); the "
+                                        "state lives in registers, real traffic is the parameter load and 17 output rows")}
+        rv = B.valu_roofline('state_packed_cascade20_' + label, ms, steps)
+        if rv:
+            r["roofline_valu_issue"] = rv
+        out[label] = r
+    if cpu:
+        out["cpu_baseline"] = B.cpu_baseline(gm, theta, budget_s=5.0, sens=False)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# configs[3]: 8 experiment settings x 1024 vectors, residual + Jacobian assembly
+# ---------------------------------------------------------------------------
+def _config3(model):
+    from sysbio_modeling_amd import models_zoo
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        p4, th4 = models_zoo.cascade_config4_project(model)
+    return p4, th4, models_zoo.config4_ensemble(th4, 1024)
+
+
+def run_configs3(model, gm, dev, reps=3, cpu=True):
+    import torch
+    from sysbio_modeling_amd import _lib, models_zoo
+    p4, th4, thetas = _config3(model)
+    t4 = torch.from_numpy(thetas).to(dev)
+    V, E = thetas.shape[0], 8
+    holder = {}
+
+    def go():
+        holder['o'] = p4.evaluate_batch(t4, jacobian=True, want=('jacobian',))
+    ms = _events(torch, dev, go, reps)
+    o4 = holder['o']
+    steps = int(o4['n_steps'].sum().item())
+    # the integrator kernel of that pass alone: the same V*E trajectories through sbm_sens_batch
+    a = p4.descriptor_arrays()
+    pmap, pfixed = np.asarray(a['pmap']), np.asarray(a['pfixed'])
+    Pall = np.where(pmap[None] >= 0, np.exp(thetas[:, np.maximum(pmap, 0)]), pfixed[None])      # (V, E, n_par)
+    Pd = torch.from_numpy(np.ascontiguousarray(Pall.reshape(V * E, -1))).to(dev)
+    grid = np.linspace(0, models_zoo.CASCADE_T_END, 1000)
+    tg = torch.from_numpy(np.concatenate([[0.0], grid[np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)]])).to(dev)
+    dm = model.device_model
+    Yk = torch.empty((V * E, len(tg), 20), dtype=torch.float64, device=dev)
+    Sk = torch.empty((V * E, len(tg), 20, 40), dtype=torch.float64, device=dev)
+    nk = torch.empty((V * E,), dtype=torch.int32, device=dev)
+    opts = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+    k_ms = _events(torch, dev, lambda: dm.sens_dev(Pd, tg, None, opts, Yk, Sk, None, nk, None), reps)
+    k_steps = int(nk.sum().item())
+    out = {"workload": "configs[3]: 8 experiment settings x 1024 vectors (8192 trajectories of 820 ODEs), residuals + "
+                       "Jacobian: 512 rows x 68 parameters per vector, 4 scale factors; on ONE GPU (the driver's "
+                       "multi-GPU run shards the vector axis of the headline workload the same way)",
+           "ms": ms, "steps": steps, "value": steps / (ms * 1e-3), "unit": "ODE-steps/s", "rows": 512, "params": 68,
+           "failed_vectors": int((o4['status'] != 0).sum().item()),
+           "roofline": B.hbm_roofline("sbm_sens_rowgroup_kernel<cascade20,dopri45>", 'sens_rowgroup_cascade20_dopri45',
+                                      k_ms, k_steps, B.BYTES_PER_STEP,
+                                      "the pass's integrator launch alone (8192 trajectories), 13 120 B per accepted step"),
+           "integrator_share_of_pass": k_ms / ms}
+    rv = B.valu_roofline('sens_rowgroup_cascade20_dopri45', k_ms, k_steps)
+    if rv:
+        out["roofline_valu_issue"] = rv
+    if cpu:
+        from oracle import tolerances as tol
+        po = B.project_oracle_of(gm, p4)
+        # parity of the timed pass on two vectors, then the timed sample
+        R = o4['residuals'].cpu().numpy()
+        J = o4['jacobian'].cpu().numpy()
+        worst = [0.0, 0.0]
+        for v in (0, V - 1):
+            rr, sims, Bf = po.residuals(thetas[v], return_parts=True)
+            Jm = po.model_jacobian(thetas[v])
+            Jr = po.calc_project_jacobian(thetas[v])
+            ts, tj = tol.lsoda_taus(a, thetas[v], sims, Jm)
+            t = tol.project_tolerances(a, sims, Bf, ts, Jm, tj)
+            worst[0] = max(worst[0], tol.tol_ratio(R[v], rr, t['residuals']))
+            worst[1] = max(worst[1], tol.tol_ratio(J[v], Jr, t['jacobian']))
+        po.lsoda_steps = 0
+        n, t0 = 0, time.perf_counter()
+        for v in range(1, V - 1):
+            po.calc_project_jacobian(thetas[v])
+            n += 1
+            if time.perf_counter() - t0 > 10.0:
+                break
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": po.lsoda_steps / dt, "unit": "ODE-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d project vectors (8 experiments each): ProjectOracle.calc_project_jacobian = odeint "
+                      "rtol=atol=1e-10 on the 1000-point grid per experiment + numpy assembly; %.1f s, %d LSODA steps"
+                      % (n, dt, po.lsoda_steps),
+            "ms_per_vector": 1e3 * dt / max(n, 1),
+            "parity_of_timed_pass": {"vectors_checked": 2, "residual_err_in_tolerance_units": worst[0],
+                                     "jacobian_err_in_tolerance_units": worst[1],
+                                     "tolerance": "oracle/tolerances.py::project_tolerances over lsoda_taus"}}
+    return out
+
+
+# ---------------------------------------------------------------------------
+# configs[4]: stiff 50-state cascade (2550 coupled ODEs), 4096 vectors
+# ---------------------------------------------------------------------------
+def stiff_pass(torch, dev, dm, P5, t5, bufs):
+    """One evaluation of the 4096-vector stiff ensemble AT THE PARITY-MEETING SETTING (tests/test_gpu_implicit.py:
+    within 1e-8 |ref| + 5e-9 of the real reference's LSODA results): see STIFF_SETTING."""
+    from sysbio_modeling_amd import _lib, models_zoo
+    Yc, Sc, Yf, Sf, st, ns, nw, st2, ns2, nw2 = bufs
+    o1 = _lib.make_opts('implicit_midpoint', rtol=1e-10, atol=1e-12, n_steps=4096, t_end=models_zoo.STIFF_T_END, step_mult=1)
+    o2 = _lib.make_opts('implicit_midpoint', rtol=1e-10, atol=1e-12, n_steps=4096, t_end=models_zoo.STIFF_T_END, step_mult=2)
+    dm.sens_dev(P5, t5, None, o1, Yc, Sc, st, ns, nw)
+    dm.sens_dev(P5, t5, None, o2, Yf, Sf, st2, ns2, nw2)
+    # Richardson: the symmetric rule's error expands in h^2
+    torch.add(Yf, Yf - Yc, alpha=1.0 / 3.0, out=Yf)
+    torch.add(Sf, Sf - Sc, alpha=1.0 / 3.0, out=Sf)
+    return Yf, Sf
+
+
+STIFF_SETTING = "implicit midpoint, 4096 + 8192 fixed steps, Richardson-extrapolated on the device"
+
+
+def run_configs4(model, gm, dev, reps=3, cpu=True):
+    import torch
+    import os
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.symbolic import zoo_model
+    from sysbio_modeling_amd.model import OdeModel
+    gm5 = zoo_model('stiff50')
+    m5 = OdeModel(gm5.model, gm5.sens_model, gm5.n_vars, gm5.param_order, use_jit=False)
+    m5.enable_jit(model.device_model.ctx)
+    dm = m5.device_model
+    V = 4096
+    theta5, Pn = models_zoo.stiff_ensemble(V)
+    g = np.load(os.path.join(B.REPO, 'tests', 'golden', 'stiff50_ref.npz'))
+    assert np.array_equal(Pn[:3], g['P'])
+    P5 = torch.from_numpy(Pn).to(dev)
+    t_np = np.concatenate([[0.0], g['t'][g['idx']]])
+    t5 = torch.from_numpy(t_np).to(dev)
+    nt = len(t_np)
+    f64, i32 = torch.float64, torch.int32
+    bufs = (torch.empty((V, nt, 50), dtype=f64, device=dev), torch.empty((V, nt, 50, 50), dtype=f64, device=dev),
+            torch.empty((V, nt, 50), dtype=f64, device=dev), torch.empty((V, nt, 50, 50), dtype=f64, device=dev)) + \
+        tuple(torch.empty((V,), dtype=i32, device=dev) for _ in range(6))
+    holder = {}
+
+    def go():
+        holder['YS'] = stiff_pass(torch, dev, dm, P5, t5, bufs)
+    ms = _events(torch, dev, go, reps)
+    Yg, Sg = holder['YS']
+    steps = int(bufs[5].sum().item()) + int(bufs[8].sum().item())
+    newton = int(bufs[6].sum().item()) + int(bufs[9].sum().item())
+    failed = int(((bufs[4] != 0) | (bufs[7] != 0)).sum().item())
+    # parity of the timed pass against the REAL reference's LSODA results (tests/golden/stiff50_ref.npz: 3 vectors)
+    from oracle.tolerances import parity_err
+    ey = parity_err(Yg[:3, 1:].cpu().numpy(), g['Y'])
+    es = parity_err(Sg[:3, 1:].cpu().numpy().reshape(3, nt - 1, 2500), g['S'])
+    out = {"workload": "configs[4]: stiff50 (50 states, 50 sensitivity parameters: 2550 coupled ODEs, rates spanning "
+                       "1e6), 4096 vectors, 16 output times, " + STIFF_SETTING,
+           "ms": ms, "steps": steps, "value": steps / (ms * 1e-3), "unit": "ODE-steps/s",
+           "vectors_per_s": V / (ms * 1e-3), "launches_per_pass": 2, "newton_iterations_per_step": 1.0 + newton / max(steps, 1),
+           "failed_vectors": failed,
+           "parity_of_timed_pass": {"vectors_checked": 3, "state_err_in_tolerance_units": ey,
+                                    "sens_err_in_tolerance_units": es,
+                                    "tolerance": "|gpu - ref| <= 1e-8 |ref| + 5e-9 against the real reference "
+                                                 "OdeModel's results (tests/golden/stiff50_ref.npz)"},
+           "roofline": B.hbm_roofline("sbm_imid_kernel<stiff50>", 'imid_stiff50', ms, steps, 2 * 8 * 2550,
+                                      "SURVEY.md section 8(d): 40 800 B per step under the state-streaming model; a "
+                                      "fraction above 1 only says that a streaming integrator could not run this "
+                                      "fast -- the kernel is register-resident, see roofline_valu_issue")}
+    rv = B.valu_roofline('imid_stiff50', ms, steps)
+    if rv:
+        out["roofline_valu_issue"] = rv
+    if cpu:
+        # LSODA on the 2550-equation system differences (and factors) a dense 2550 x 2550 Jacobian: 45 - 150 s per
+        # vector on one core.  The bounded sample is ONE vector over the first tenth of the time span (the first 100
+        # of the reference's 1000 grid points); the rate is steps per second either way.
+        from oracle import odeint_oracle as oo
+        gm5.c_library()
+        t0 = time.perf_counter()
+        (_, _), info = oo.calc_jacobian(gm5, Pn[3], g['t'][:101], use_c=True, return_states=True, full_output=True)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": int(info['nst'][-1]) / dt, "unit": "ODE-steps/s", "cores": 1, "kind": "port",
+            "sample": "1 vector (#3 of the ensemble) over t in [0, 1] (the first 100 of the 1000 grid points; the whole "
+                      "span takes 45 - 150 s per vector): scipy.integrate.odeint rtol=atol=1e-10, 2550 ODEs, compiled C "
+                      "RHS, Dfun=None as in the reference's default call; %.1f s, %d LSODA steps, %d Jacobian "
+                      "evaluations" % (dt, int(info['nst'][-1]), int(info['nje'][-1]))}
+    return out
+
+
+# ---------------------------------------------------------------------------
+# end-to-end fitting
+# ---------------------------------------------------------------------------
+def run_fit(model, gm, dev, reps=1, cpu=True):
+    """fits/s of Project.fit_batch (multi-start Levenberg-Marquardt, everything on the device) on the configs[3]
+    project with noise-free data, against the reference's pattern
+    leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian) (tests/test_Project.py:202-213,351-357) run
+    serially on the CPU oracle; the optima are compared."""
+    import torch
+    from sysbio_modeling_amd import models_zoo
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        proj, th0 = models_zoo.cascade_config4_project(model, noise=0.0, reference_compat=False)
+    n_starts = 256
+    starts = th0[None, :] + 0.15 * np.random.default_rng(1).standard_normal((n_starts, th0.size))
+    proj.fit_batch(starts[:8], max_iter=3)            # warm-up (scratch allocation)
+    torch.cuda.synchronize(dev)
+    best = None
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        fit = proj.fit_batch(starts, max_iter=40)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out = {"workload": "multi-start least-squares fit of the configs[3] project (8 experiments, 512 residual rows, "
+                       "68 parameters, noise-free data): %d starts at 0.15 log-units from the optimum, "
+                       "Project.fit_batch, max 40 iterations" % n_starts,
+           "seconds": best, "fits_per_s": n_starts / best, "starts": n_starts,
+           "converged": int(fit['converged'].sum()), "cost_median": float(np.median(fit['cost'])),
+           "cost_max": float(np.max(fit['cost'])), "evaluations": int(fit['n_evaluations']),
+           "distance_to_truth_max": float(np.max(np.abs(fit['theta'][fit['converged']] - th0[None, :])))
+           if fit['converged'].any() else None}
+    if cpu:
+        from scipy.optimize import leastsq
+        from oracle.project_oracle import ProjectOracle
+        po = ProjectOracle(gm, list(proj.experiments), proj._model_parameter_settings,
+                           dict(proj._measurement_to_model_map_raw),
+                           sf_groups=['s%d' % v for v in models_zoo.CASCADE_MEASURED_SPECIES], reference_compat=False)
+        calls = [0, 0]
+
+        def res(x):
+            calls[0] += 1
+            return po.residuals(x)
+
+        def jac(x):
+            calls[1] += 1
+            return po.calc_project_jacobian(x)
+        t0 = time.perf_counter()
+        x, _, info, _, ier = leastsq(res, starts[0], Dfun=jac, full_output=True, maxfev=60)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": 1.0 / dt, "unit": "fits/s", "cores": 1, "kind": "port",
+            "sample": "ONE start (#0): scipy.optimize.leastsq(residuals, x0, Dfun=calc_project_jacobian, maxfev=60) "
+                      "over the CPU oracle; %.1f s, %d residual + %d Jacobian evaluations, ier=%d"
+                      % (dt, calls[0], calls[1], ier),
+            "cost": float(0.5 * np.sum(res(x) ** 2)),
+            "distance_to_truth": float(np.max(np.abs(x - th0))),
+            "distance_to_gpu_optimum_of_same_start": float(np.max(np.abs(x - fit['theta'][0])))}
+        out["speedup_vs_one_core"] = out["fits_per_s"] / out["cpu_baseline"]["value"]
+    return out
+
+
+# ---------------------------------------------------------------------------
+# kernel variants side by side (no CPU leg: same workload as the headline)
+# ---------------------------------------------------------------------------
+def variant_extras(model, dev, theta_p, tg, rk4_steps):
+    import torch
+    from sysbio_modeling_amd import _lib
+    dm = model.device_model
+    V = theta_p.shape[0]
+    Yk = torch.empty((V, len(tg), 20), dtype=torch.float64, device=dev)
+    Sk = torch.empty((V, len(tg), 20, 40), dtype=torch.float64, device=dev)
+    ns = torch.empty((V,), dtype=torch.int32, device=dev)
+
+    def t(o):
+        ms = _events(torch, dev, lambda: dm.sens_dev(theta_p, tg, None, o, Yk, Sk, None, ns, None), 3)
+        st = int(ns.sum().item())
+        return {"ms": ms, "steps": st, "steps_per_s": st / (ms * 1e-3)}
+    ex = {}
+    for variant in ('auto', 'row_lane', 'per_wave'):
+        ex["sens_dopri45_%s" % variant] = t(_lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant=variant))
+        ex["sens_rk4_fixed_%d_%s" % (rk4_steps, variant)] = t(_lib.make_opts('rk4', n_steps=rk4_steps, t_end=100.0,
+                                                                             variant=variant))
+    # a model beyond one row / one column per lane: 70 states, 140 parameters, 9870 coupled ODEs per trajectory
+    try:
+        from sysbio_modeling_amd import models_zoo
+        from sysbio_modeling_amd.symbolic import GeneratedModel
+        from sysbio_modeling_amd.model import OdeModel
+        gm7 = GeneratedModel(models_zoo.cascade_spec(70, name='cascade70'))
+        m7 = OdeModel(gm7.model, gm7.sens_model, gm7.n_vars, gm7.param_order, use_jit=False)
+        m7.enable_jit(dm.ctx)
+        V7 = 1024
+        P7 = torch.from_numpy(models_zoo.cascade_ensemble(V7, n=70, spread=0.3)[1]).to(dev)
+        t7 = torch.tensor([50.0, 100.0], dtype=torch.float64, device=dev)
+        Y7 = torch.empty((V7, 2, 70), dtype=torch.float64, device=dev)
+        S7 = torch.empty((V7, 2, 70, 140), dtype=torch.float64, device=dev)
+        st7 = torch.empty((V7,), dtype=torch.int32, device=dev)
+        ns7 = torch.empty((V7,), dtype=torch.int32, device=dev)
+        o7 = _lib.make_opts(**{k: v for k, v in m7.integrator_options.items() if k in ('method', 'rtol', 'atol')})
+        ms7 = _events(torch, dev, lambda: m7.device_model.sens_dev(P7, t7, None, o7, Y7, S7, st7, ns7, None), 1)
+        n7 = int(ns7.sum().item())
+        ex["large_model_cascade70_dopri45"] = {
+            "ms": ms7, "steps": n7, "steps_per_s": n7 / (ms7 * 1e-3), "n_equations": 70 + 70 * 140, "vectors": V7,
+            "rtol": o7.rtol, "algorithmic_GBps": n7 / (ms7 * 1e-3) * 2 * 8 * (70 + 70 * 140) / 1e9,
+            "failed_vectors": int((st7 != 0).sum().item())}
+    except Exception as e:   # noqa: BLE001
+        ex["large_model_cascade70_dopri45"] = {"error": repr(e)[:200]}
+    return ex
+
+
+RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'fit': run_fit}
+ORDER = ['configs1', 'configs3', 'configs4', 'fit']

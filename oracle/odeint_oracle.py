@@ -114,19 +114,22 @@ def calc_jacobian(sens_model, experiment_params, t_sim, init_conditions=None, n_
     return (res, info) if full_output else res
 
 
-def tight_solution(gm, experiment_params, t_sim, sens=True):
+def tight_solution(gm, experiment_params, t_sim, sens=True, use_c=False, atol=1e-16):
     """Independent high-accuracy solution (DOP853, rtol 1e-13) used to tell
-    'GPU more accurate than LSODA' from 'GPU wrong' (SURVEY.md section 8(d))."""
+    'GPU more accurate than LSODA' from 'GPU wrong' (SURVEY.md section 8(d)).  Returns (len(t_sim), N)
+    with N = n (+ n k with ``sens``); t_sim[0] is the initial time, y(t_sim[0]) = 0."""
     from scipy.integrate import solve_ivp
     n, k = gm.n_vars, gm.n_sens
     N = n + n * k if sens else n
-    p = np.ascontiguousarray(experiment_params, dtype=np.float64)
-    yout = np.zeros(N)
-    fn = gm.sens_model if sens else gm.model
+    if use_c:
+        lib = gm.c_library()
+        fw = _wrap_c(lib.sbm_sens_rhs if sens else lib.sbm_rhs, N, experiment_params)
+    else:
+        fw = _wrap(gm.sens_model if sens else gm.model, N, experiment_params)
 
     def f(t, y):
-        fn(y, t, yout, p)
-        return yout.copy()
-    sol = solve_ivp(f, (0.0, float(t_sim[-1])), np.zeros(N), method='DOP853', t_eval=np.asarray(t_sim),
-                    rtol=1e-13, atol=1e-16)
+        return fw(y, t).copy()
+    t_sim = np.asarray(t_sim, dtype=float)
+    sol = solve_ivp(f, (float(t_sim[0]), float(t_sim[-1])), np.zeros(N), method='DOP853', t_eval=t_sim,
+                    rtol=1e-13, atol=atol)
     return sol.y.T

@@ -175,10 +175,13 @@ class ProjectOracle(object):
         for ei, exp in enumerate(self.experiments):
             p = self.experiment_parameters(ei, theta)
             t_sim = self._t_sim(exp)
+            # (full_output only to count LSODA's steps for the CPU baseline of bench.py: same call, same numbers)
             if with_jacobian:
-                S, Y = odeint_oracle.calc_jacobian(self.gm, p, t_sim, use_c=self.use_c, return_states=True)
+                (S, Y), info = odeint_oracle.calc_jacobian(self.gm, p, t_sim, use_c=self.use_c, return_states=True,
+                                                           full_output=True)
             else:
-                Y = odeint_oracle.simulate(self.gm, p, t_sim, use_c=self.use_c)
+                Y, info = odeint_oracle.simulate(self.gm, p, t_sim, use_c=self.use_c, full_output=True)
+            self.lsoda_steps = getattr(self, 'lsoda_steps', 0) + int(info['nst'][-1])
             for m in exp.measurements:
                 mtype, margs = self.mmap[m.variable_name]
                 _, _, tps = m.get_nonzero_measurements()

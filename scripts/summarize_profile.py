@@ -2,26 +2,49 @@
 
 usage: python scripts/summarize_profile.py gpurun_out/<tag> profiles/<round>
 
-  <round>/kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
-  <round>/pmc_summary.json   per kernel: launch resources + mean of every collected counter per launch
-  profiles/hbm_traffic.json  HBM bytes per launch of the dominant sensitivity kernel (bench.py's
-                             roofline.traffic): (2*FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled as
-                             MI355X_MICROARCH.md's HBM section prescribes for gfx950, separate passes.
+  <round>/<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+  <round>/<workload>_pmc_summary.json   per kernel: launch resources + mean of every collected counter per launch
+  <round>/<workload>_plain.json         the un-profiled `bench.py --only <workload>` line (steps per pass)
+  profiles/kernel_counters.json         what bench.py's roofline objects read, per kernel key:
+        hbm_bytes_per_launch   (2*FETCH_SIZE + WRITE_SIZE) KiB per pass of the workload -- FETCH_SIZE doubled as
+                               MI355X_MICROARCH.md's HBM section prescribes for gfx950, separate PMC passes
+        valu_insts_per_step    SQ_INSTS_VALU / accepted steps
+        cycles_per_valu_inst   4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU   (the counter ticks in quad-cycles)
+        valu_busy_fraction     SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES * resident waves per SIMD  (= share of the SIMD's
+                               issue slots; waves per SIMD from the launch's register allocation)
+        lds_conflict_share     SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
 import collections
 import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
+# key -> (workload, kernel-name regex, path of "steps per pass" inside the workload's plain.json, launches per pass)
+KEYS = {
+    'sens_rowgroup_cascade20_dopri45': ('headline', r'sbm_sens_rowgroup_kernel<.*, 1>', ('headline', 'steps_per_pass'), 1),
+    'state_packed_cascade20_dopri45': ('configs1', r'sbm_state_packed_kernel<.*, 1, ', ('configs1', 'dopri45', 'steps'), 1),
+    'state_packed_cascade20_rk4_fixed_4096': ('configs1', r'sbm_state_packed_kernel<.*, 0, ', ('configs1', 'rk4_fixed_4096', 'steps'), 1),
+    'imid_stiff50': ('configs4', r'sbm_imid', ('configs4', 'steps'), None),
+    'lm_step': ('fit', r'k_lm_step', None, None),
+    'assemble': ('headline', r'k_assemble', None, 1),
+    'dense20_valu': ('dense', r'sbm_sens_rowlane_kernel', ('dense', 'valu', 'steps'), 1),
+    'dense20_mfma': ('dense', r'sbm_sens_mfma_kernel', ('dense', 'mfma', 'steps'), 1),
+}
 
-def main(src, dst):
-    os.makedirs(dst, exist_ok=True)
-    ks = glob.glob(os.path.join(src, 'trace', '**', '*_kernel_stats.csv'), recursive=True)
-    if ks:
-        shutil.copy(ks[0], os.path.join(dst, 'kernel_stats.csv'))
+
+def waves_per_simd(vgpr, agpr):
+    try:
+        alloc = -(-(int(vgpr) + int(agpr or 0)) // 8) * 8
+    except (TypeError, ValueError):
+        return None
+    return max(1, min(8, 512 // max(alloc, 1)))
+
+
+def read_pmc(src):
     summary = collections.OrderedDict()
     for f in sorted(glob.glob(os.path.join(src, 'pmc_*', '**', '*_counter_collection.csv'), recursive=True)):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -37,30 +60,92 @@ def main(src, dst):
         for k, d in per.items():
             e = summary.setdefault(k, collections.OrderedDict(launch=launch[k]))
             for c, v in sorted(d.items()):
-                e[c] = {'launches': len(v), 'mean_per_launch': sum(v) / len(v)}
-    with open(os.path.join(dst, 'pmc_summary.json'), 'w') as fh:
-        json.dump(summary, fh, indent=1)
-    # dominant sensitivity kernel = the one with the largest WRITE_SIZE total
-    best = None
-    for k, e in summary.items():
-        if 'sbm_sens' in k and 'WRITE_SIZE' in e and 'FETCH_SIZE' in e:
-            tot = e['WRITE_SIZE']['mean_per_launch'] * e['WRITE_SIZE']['launches']
-            if best is None or tot > best[0]:
-                best = (tot, k, e)
-    if best:
-        _, k, e = best
-        fetch, write = e['FETCH_SIZE']['mean_per_launch'], e['WRITE_SIZE']['mean_per_launch']
-        tpath = os.path.join(os.path.dirname(os.path.abspath(dst)), 'hbm_traffic.json')
-        out = {'dopri45': {
-            'hbm_bytes_per_launch': (2.0 * fetch + write) * 1024.0, 'fetch_kib': fetch, 'write_kib': write,
-            'note': "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), %s, V=4096, 17 output rows; "
-                    "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md "
-                    "section HBM; the read side is scalar / 8-byte traffic, so this is an upper bound). Writes = the "
-                    "sampled Y/S rows: 4096*17*820*8 B = 456.7e6 B." % k,
-            'source': os.path.join(dst, 'pmc_summary.json')}}
-        with open(tpath, 'w') as fh:
-            json.dump(out, fh, indent=1)
-    print("wrote", dst, "kernels:", len(summary))
+                e[c] = {'launches': len(v), 'mean_per_launch': sum(v) / len(v), 'total': sum(v)}
+    return summary
+
+
+def dig(d, path):
+    for p in path:
+        d = d[p]
+    return d
+
+
+def main(src, dst):
+    os.makedirs(dst, exist_ok=True)
+    cpath = os.path.join(os.path.dirname(os.path.abspath(dst)), 'kernel_counters.json')
+    try:
+        with open(cpath) as fh:
+            counters = json.load(fh)
+    except (OSError, ValueError):
+        counters = {}
+    for wdir in sorted(glob.glob(os.path.join(src, '*', ''))):
+        w = os.path.basename(os.path.dirname(wdir))
+        ks = glob.glob(os.path.join(wdir, 'trace', '**', '*_kernel_stats.csv'), recursive=True)
+        if ks:
+            shutil.copy(ks[0], os.path.join(dst, '%s_kernel_stats.csv' % w))
+        plain = None
+        try:
+            with open(os.path.join(wdir, 'plain.json')) as fh:
+                plain = json.loads([ln for ln in fh if ln.startswith('{')][-1])
+            with open(os.path.join(dst, '%s_plain.json' % w), 'w') as fh:
+                json.dump(plain, fh, indent=1)
+        except (OSError, ValueError, IndexError):
+            pass
+        summary = read_pmc(wdir)
+        if not summary:
+            continue
+        with open(os.path.join(dst, '%s_pmc_summary.json' % w), 'w') as fh:
+            json.dump(summary, fh, indent=1)
+        for key, (kw, rx, steps_path, per_pass) in KEYS.items():
+            if kw != w:
+                continue
+            hits = [k for k in summary if re.search(rx, k)]
+            if not hits:
+                continue
+            # several instantiations may match (e.g. two chunk layouts): take the one with most VALU work
+            k = max(hits, key=lambda kk: summary[kk].get('SQ_INSTS_VALU', {}).get('total', 0.0))
+            e = summary[k]
+            out = {'kernel': k, 'launch': e['launch'], 'source': os.path.join(dst, '%s_pmc_summary.json' % w)}
+            n_launch = e.get('SQ_INSTS_VALU', e.get('WRITE_SIZE', {'launches': 0}))['launches']
+            steps_pass = None
+            if plain is not None and steps_path is not None:
+                try:
+                    steps_pass = float(dig(plain, steps_path))
+                except (KeyError, TypeError):
+                    steps_pass = None
+            lpp = per_pass
+            if lpp is None and plain is not None:
+                try:
+                    lpp = float(plain[w].get('launches_per_pass', 1))
+                except (KeyError, AttributeError):
+                    lpp = 1
+            lpp = lpp or 1
+            if 'FETCH_SIZE' in e and 'WRITE_SIZE' in e:
+                f_, w_ = e['FETCH_SIZE']['mean_per_launch'], e['WRITE_SIZE']['mean_per_launch']
+                out['hbm_bytes_per_launch'] = (2.0 * f_ + w_) * 1024.0 * lpp
+                out['fetch_kib_per_launch'], out['write_kib_per_launch'] = f_, w_
+                out['launches_per_pass'] = lpp
+            if 'SQ_INSTS_VALU' in e and e['SQ_INSTS_VALU']['total'] > 0:
+                iv = e['SQ_INSTS_VALU']
+                av = e.get('SQ_ACTIVE_INST_VALU')
+                if steps_pass:
+                    out['valu_insts_per_step'] = iv['mean_per_launch'] * lpp / steps_pass
+                if av:
+                    out['cycles_per_valu_inst'] = 4.0 * av['total'] / iv['total']
+                    wc = e.get('SQ_WAVE_CYCLES')
+                    wps = waves_per_simd(e['launch']['vgpr'], e['launch']['agpr'])
+                    if wc and wps:
+                        out['waves_per_simd_by_registers'] = wps
+                        out['valu_active_share_of_wave_lifetime'] = av['total'] / wc['total']
+                        out['valu_busy_fraction'] = min(1.0, av['total'] / wc['total'] * wps)
+            if 'SQ_LDS_BANK_CONFLICT' in e and e.get('SQ_LDS_IDX_ACTIVE', {}).get('total'):
+                out['lds_conflict_share'] = e['SQ_LDS_BANK_CONFLICT']['total'] / e['SQ_LDS_IDX_ACTIVE']['total']
+                if 'SQ_INSTS_LDS' in e and steps_pass:
+                    out['lds_insts_per_step'] = e['SQ_INSTS_LDS']['mean_per_launch'] * lpp / steps_pass
+            counters[key] = out
+    with open(cpath, 'w') as fh:
+        json.dump(counters, fh, indent=1)
+    print("wrote", dst, "and", cpath, "keys:", sorted(counters))
 
 
 if __name__ == '__main__':

@@ -38,11 +38,77 @@ def _run(cmd, what):
     return proc.stdout
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
+_hipcc_id = None
+
+
+def _toolchain_id():
+    """What besides the sources decides the bytes of a build: compiler version and target."""
+    global _hipcc_id
+    if _hipcc_id is None:
+        try:
+            ver = subprocess.run([hipcc_path(), '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                 text=True).stdout
+        except Exception:   # noqa: BLE001
+            ver = '?'
+        _hipcc_id = hashlib.sha1((ver + OFFLOAD_ARCH).encode()).hexdigest()[:12]
+    return _hipcc_id
+
+
+def _stamp_of(cmd, sources):
+    """Fingerprint of one build: flags + toolchain + contents of every source."""
+    h = hashlib.sha1()
+    h.update(_toolchain_id().encode())
+    # (paths relative to the repository: the snapshot on a GPU box lives under another root)
+    h.update('\0'.join(c.replace(REPO_DIR, '<repo>') for c in cmd[1:]).encode())
+    for s in sources:
+        with open(s, 'rb') as fh:
+            h.update(hashlib.sha1(fh.read()).digest())
+    return h.hexdigest()
+
+
+def _up_to_date(target, stamp):
+    try:
+        with open(target + '.stamp') as fh:
+            return os.path.exists(target) and fh.read().strip() == stamp
+    except OSError:
         return False
-    t = os.path.getmtime(target)
-    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _locked_build(target, cmd_for, sources, what, force=False):
+    """Build ``target`` with ``cmd_for(tmp_out)`` unless its stamp (flags, toolchain, source contents) is current.
+    Safe with one process per GPU starting cold at once: an fcntl lock serialises the builders of one target, the
+    compiler writes to a private name and the result is moved into place atomically -- a concurrent dlopen
+    sees the old file or the new one, never a half-written one.  When hipcc is absent (a box that only runs
+    prebuilt files) an existing target is used as it is."""
+    import fcntl
+    ref_cmd = cmd_for(target)
+    try:
+        stamp = _stamp_of(ref_cmd, sources)
+    except BuildError:
+        if os.path.exists(target) and not force:
+            return target
+        raise
+    if not force and _up_to_date(target, stamp):
+        return target
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    with open(target + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _up_to_date(target, stamp):     # another process built it while we waited
+                return target
+            tmp = '%s.%d.tmp' % (target, os.getpid())
+            try:
+                _run(cmd_for(tmp), what)
+                os.replace(tmp, target)
+                with open(target + '.stamp.tmp%d' % os.getpid(), 'w') as fh:
+                    fh.write(stamp)
+                os.replace(target + '.stamp.tmp%d' % os.getpid(), target + '.stamp')
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return target
 
 
 def _core_sources():
@@ -53,15 +119,11 @@ def _core_sources():
 
 def build_core(force=False, extra_flags=()):
     """libsbm_hip.so: C ABI, contexts, model loading, project assembly kernels."""
-    os.makedirs(BUILD_DIR, exist_ok=True)
-    srcs = _core_sources()
-    if not force and _newer(CORE_LIB, srcs):
-        return CORE_LIB
-    cmd = [hipcc_path(), '--offload-arch=' + OFFLOAD_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wall', '-Wno-unused-function', *extra_flags,
-           os.path.join(CSRC_DIR, 'sbm_core.hip'), '-o', CORE_LIB, '-ldl']
-    _run(cmd, 'build of libsbm_hip.so')
-    return CORE_LIB
+    def cmd_for(out):
+        return [hipcc_path(), '--offload-arch=' + OFFLOAD_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
+                '-Wall', '-Wno-unused-function', *extra_flags,
+                os.path.join(CSRC_DIR, 'sbm_core.hip'), '-o', out, '-ldl']
+    return _locked_build(CORE_LIB, cmd_for, _core_sources(), 'build of libsbm_hip.so', force)
 
 
 def plugin_path(name):
@@ -80,13 +142,11 @@ def build_plugin(name, header_path, force=False, extra_flags=()):
     srcs = [header_path, os.path.join(CSRC_DIR, 'sbm_plugin_main.hip'),
             os.path.join(CSRC_DIR, 'sbm_integrators.hpp'), os.path.join(CSRC_DIR, 'sbm_plugin.h'),
             os.path.join(REPO_DIR, 'include', 'sbm.h')]
-    if not force and _newer(out, srcs):
-        return out
-    cmd = [hipcc_path(), '--offload-arch=' + OFFLOAD_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-DSBM_MODEL_HEADER="%s"' % os.path.abspath(header_path), *extra_flags,
-           os.path.join(CSRC_DIR, 'sbm_plugin_main.hip'), '-o', out]
-    _run(cmd, 'build of model plugin %s' % name)
-    return out
+    def cmd_for(o):
+        return [hipcc_path(), '--offload-arch=' + OFFLOAD_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
+                '-DSBM_MODEL_HEADER="%s"' % os.path.abspath(header_path), *extra_flags,
+                os.path.join(CSRC_DIR, 'sbm_plugin_main.hip'), '-o', o]
+    return _locked_build(out, cmd_for, srcs, 'build of model plugin %s' % name, force)
 
 
 def build_c_rhs(name, c_source, force=False):

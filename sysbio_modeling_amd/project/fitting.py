@@ -43,7 +43,7 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
         raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
                          "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
     lib = _lib.load_library()
-    ctx = _lib.default_context()
+    ctx = project._model.device_model.ctx      # the context (device, stream) the project's model lives on
     th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
     th = th.clone()
     dev = th.device

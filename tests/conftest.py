@@ -9,23 +9,16 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
-# parity tolerance of the integration path, stated once (DESIGN.md section "Parity"):
-# the reference answer is SciPy odeint at rtol = atol = 1e-10 (model/ode_model.py:123,168),
-# itself only ~1e-9 accurate in ABSOLUTE terms (atol term); two correct solvers therefore
-# agree to 1e-8 relative plus LSODA's own absolute noise.
-PARITY_RTOL = 1e-8
-PARITY_ATOL = 5e-9
+# the parity tolerances are stated once, in oracle/tolerances.py (checker infrastructure):
+#   parity_err  -- against the reference's LSODA: |gpu - ref| <= 1e-8 |ref| + 5e-9 (LSODA's own absolute noise)
+#   survey_err  -- against a tight solution: SURVEY.md section 8(d), |gpu - ref| <= 1e-8 max(|ref|, 1e-6 colmax)
+#   project_tolerances -- first-order propagation of either through the assembly formulas
+from oracle.tolerances import (PARITY_RTOL, PARITY_ATOL, parity_err, survey_err, survey_tol, tol_ratio,  # noqa: E402,F401
+                               lsoda_taus, tight_taus, project_tolerances)
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-def parity_err(a, b):
-    """max |a-b| / (PARITY_ATOL + PARITY_RTOL |b|): <= 1 means within the stated tolerance."""
-    a = np.asarray(a, dtype=float)
-    b = np.asarray(b, dtype=float)
-    return float(np.max(np.abs(a - b) / (PARITY_ATOL + PARITY_RTOL * np.abs(b)))) if a.size else 0.0
 
 
 @pytest.fixture(scope='session')
