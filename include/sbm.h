@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SBM_ABI_VERSION 1
+#define SBM_ABI_VERSION 2
 
 typedef struct sbm_ctx sbm_ctx;
 typedef struct sbm_model sbm_model;
@@ -225,9 +225,38 @@ typedef struct sbm_project_desc {
    * The reference's NormalizedSquareLossFunction (normalized_squared_loss_function.py:23-46) is
    * SBM_LOSS_SQUARE with row_sigma already multiplied by row_data on the host. */
   int32_t loss_type;
+
+  /* 'custom' measurement mappings.  The reference takes two Python callbacks there -- (parameters, map function,
+   * Jacobian map function), project/base_project.py:125-128, called per measurement at :380-383 and :461-464 --
+   * which cannot run in a kernel.  Here the observable is an EXPRESSION g(y_a, y_b, ...; t) of model variables at
+   * the sampled grid point, which the host compiles into postfix programs (SBM_OP_*):
+   *   row_prog[r] = program of the row's measure, or -1 ('direct' / 'sum': plain sum of the row's variables).
+   *   Program c lists n = prog_nvars[c] variables (the row's row_vars entries, in that order) and has 1 + n
+   *   subprograms: the value g, then dg/dy_k for k = 0..n-1; the measure's Jacobian row is
+   *   sum_k dg/dy_k * S[var_k, :] (what the reference's Jacobian map function returns, project/utils.py:29-45).
+   * prog_sub_off holds the start of every subprogram in prog_code, program after program
+   * (sum_c (1 + prog_nvars[c]) entries + 1).  All NULL / 0 without custom mappings. */
+  int32_t n_programs;
+  int32_t n_prog_code;
+  int32_t n_prog_const;
+  const int32_t* row_prog;     /* [R] */
+  const int32_t* prog_nvars;   /* [n_programs] */
+  const int32_t* prog_sub_off; /* [sum(1 + prog_nvars) + 1] */
+  const int32_t* prog_code;    /* [n_prog_code] opcodes, operands inline */
+  const double* prog_const;    /* [n_prog_const] */
+  const double* row_time;      /* [R] sampled time of each row (what SBM_OP_TIME pushes) */
 } sbm_project_desc;
 
 enum { SBM_LOSS_SQUARE = 0, SBM_LOSS_LOG_SQUARE = 1 };
+
+/* postfix programs of custom observables: a stack machine over doubles, at most SBM_PROG_MAX_STACK deep.
+ * VAR k pushes the k-th variable of the row's list, CONST i pushes prog_const[i], POWI n raises the top to the
+ * integer power n (|n| <= 64); the binary operators pop b then a and push a (op) b. */
+enum { SBM_OP_END = 0, SBM_OP_VAR = 1, SBM_OP_CONST = 2, SBM_OP_ADD = 3, SBM_OP_SUB = 4, SBM_OP_MUL = 5, SBM_OP_DIV = 6,
+       SBM_OP_NEG = 7, SBM_OP_POW = 8, SBM_OP_POWI = 9, SBM_OP_EXP = 10, SBM_OP_LOG = 11, SBM_OP_SQRT = 12,
+       SBM_OP_TANH = 13, SBM_OP_SIN = 14, SBM_OP_COS = 15, SBM_OP_ABS = 16, SBM_OP_SIGN = 17, SBM_OP_TIME = 18,
+       SBM_OP_COUNT = 19 };
+#define SBM_PROG_MAX_STACK 16
 
 int sbm_project_load(sbm_model* m, const sbm_project_desc* desc, sbm_project** out);
 int sbm_project_unload(sbm_project* p);

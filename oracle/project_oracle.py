@@ -175,26 +175,52 @@ class ProjectOracle(object):
         for ei, exp in enumerate(self.experiments):
             p = self.experiment_parameters(ei, theta)
             t_sim = self._t_sim(exp)
+            if getattr(self, 'tight', False):
+                # checker mode: DOP853 at rtol 1e-13 instead of the reference's LSODA call, at the sampled grid points
+                # only ("GPU more accurate than LSODA" must be distinguishable from "GPU wrong")
+                need = sorted(set(int(i) for m in exp.measurements
+                                  for i in np.searchsorted(t_sim, m.get_nonzero_measurements()[2])))
+                sol = odeint_oracle.tight_solution(self.gm, p, np.concatenate([[0.0], t_sim[need]]),
+                                                   sens=with_jacobian, use_c=self.use_c, atol=1e-30)[1:]
+                Y = np.full((len(t_sim), n), np.nan)
+                Y[need] = sol[:, :n]
+                if with_jacobian:
+                    S = np.full((len(t_sim), n * k), np.nan)
+                    S[need] = sol[:, n:]
             # (full_output only to count LSODA's steps for the CPU baseline of bench.py: same call, same numbers)
-            if with_jacobian:
+            elif with_jacobian:
                 (S, Y), info = odeint_oracle.calc_jacobian(self.gm, p, t_sim, use_c=self.use_c, return_states=True,
                                                            full_output=True)
             else:
                 Y, info = odeint_oracle.simulate(self.gm, p, t_sim, use_c=self.use_c, full_output=True)
-            self.lsoda_steps = getattr(self, 'lsoda_steps', 0) + int(info['nst'][-1])
+            if not getattr(self, 'tight', False):
+                self.lsoda_steps = getattr(self, 'lsoda_steps', 0) + int(info['nst'][-1])
             for m in exp.measurements:
                 mtype, margs = self.mmap[m.variable_name]
                 _, _, tps = m.get_nonzero_measurements()
                 t_idx = np.searchsorted(t_sim, tps)                  # project/utils.py:19,37,55,79
-                var_list = [margs] if mtype == 'direct' else list(margs)
-                sim = np.zeros(len(t_idx))
-                for v in var_list:                                   # utils.py:20 / :61-66
-                    sim += Y[t_idx, v]
-                sims.extend(sim)
-                times.extend(t_sim[t_idx])
+                if mtype == 'custom':
+                    # base_project.py:125-128,380-383,461-464: (parameters, map function, Jacobian map function), called
+                    # with the whole simulation.  (The reference hands the Jacobian callback only the sensitivities; a
+                    # pointwise NONLINEAR observable also needs the states, passed here as a keyword.)
+                    cpar, map_fn, jac_fn = margs
+                    sim, _ = map_fn(Y, t_sim, exp, m, cpar, True)
+                    sims.extend(sim)
+                    times.extend(t_sim[t_idx])
+                    var_list = None
+                    if with_jacobian:
+                        mj = jac_fn(S, t_sim, exp, m, cpar, True, model_sim=Y)
+                else:
+                    var_list = [margs] if mtype == 'direct' else list(margs)
+                    sim = np.zeros(len(t_idx))
+                    for v in var_list:                               # utils.py:20 / :61-66
+                        sim += Y[t_idx, v]
+                    sims.extend(sim)
+                    times.extend(t_sim[t_idx])
                 if with_jacobian:
-                    mj = np.zeros((len(t_idx), k))
-                    for v in var_list:                               # utils.py:38 / :86-88
+                    if var_list is not None:
+                        mj = np.zeros((len(t_idx), k))
+                    for v in (var_list or []):                       # utils.py:38 / :86-88
                         mj += S[t_idx, v * k:(v + 1) * k]
                     rows = np.zeros((len(t_idx), q))
                     for name in self.param_order:                    # base_project.py:469-485

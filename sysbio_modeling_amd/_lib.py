@@ -13,6 +13,7 @@ from . import build
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
+ABI_VERSION = 2      # include/sbm.h: SBM_ABI_VERSION
 SBM_RK4_FIXED = 0
 SBM_DOPRI45 = 1
 SBM_IMPLICIT_MIDPOINT = 2
@@ -42,6 +43,10 @@ class ProjectDesc(ctypes.Structure):
         ('prior_idx', c_int32_p), ('prior_mean', c_double_p), ('prior_sigma', c_double_p),
         ('sf_prior_group', c_int32_p), ('sf_prior_mean', c_double_p), ('sf_prior_sigma', c_double_p),
         ('reference_compat', ctypes.c_int32), ('loss_type', ctypes.c_int32),
+        # custom observables (postfix programs): include/sbm.h
+        ('n_programs', ctypes.c_int32), ('n_prog_code', ctypes.c_int32), ('n_prog_const', ctypes.c_int32),
+        ('row_prog', c_int32_p), ('prog_nvars', c_int32_p), ('prog_sub_off', c_int32_p), ('prog_code', c_int32_p),
+        ('prog_const', c_double_p), ('row_time', c_double_p),
     ]
 
 
@@ -103,8 +108,8 @@ def load_library(build_if_missing=True):
             fn = getattr(lib, name)  # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.sbm_abi_version() != 1:
-            raise SbmError("libsbm_hip.so ABI %d, python binding expects 1" % lib.sbm_abi_version())
+        if lib.sbm_abi_version() != ABI_VERSION:
+            raise SbmError("libsbm_hip.so ABI %d, python binding expects %d" % (lib.sbm_abi_version(), ABI_VERSION))
         _lib = lib
         return lib
 

@@ -93,6 +93,10 @@ struct sbm_project {
   DevBuf<int32_t> pmap, sens_col, tgrid_off, grid_len, row_exp, row_tidx, row_var_off, row_vars, row_sf,
       prior_idx, inv_ptr, inv_m, sfp_group;
   DevBuf<double> pfixed, tgrid, row_data, row_sigma, prior_mean, prior_sigma, sfp_mean, sfp_sigma;
+  // custom observables (postfix programs): see sbm_project_desc
+  int n_programs = 0, n_custom_weights = 0;
+  DevBuf<int32_t> row_prog, row_w0, prog_base, prog_sub_off, prog_code;
+  DevBuf<double> prog_const, row_time;
   // per-call scratch, grown on demand
   DevBuf<double> P, Y, S, sims, sf;
   DevBuf<int32_t> traj_status, traj_steps, traj_rej, goff, glen;
@@ -474,7 +478,54 @@ struct AssembleArgs {
   const double* sims_in;      // [V][R]        nullable
   const double* Jm_in;        // [V][R][q]     nullable
   const int32_t* row_plain;   // [R] nullable: 1 = row keeps the plain (s - d)/sigma form under the log loss
+  // custom observables: row_prog[r] = program or -1; row_w0[r] = first slot of the row's dg/dy weights in the LDS
+  // table (or -1); prog_base[c] = first subprogram of program c in prog_sub_off
+  int NW;                     // total weight slots (sum of the variable counts of the custom rows)
+  const int32_t *row_prog, *row_w0, *prog_base, *prog_sub_off, *prog_code;
+  const double *prog_const, *row_time;
 };
+
+// One subprogram of a custom observable: a postfix stack machine (include/sbm.h, SBM_OP_*).  The host has
+// checked every program at load time (opcodes, operand ranges, stack depth <= SBM_PROG_MAX_STACK).
+__device__ double sbm_prog_eval(const int32_t* __restrict__ code, const double* __restrict__ consts,
+                                const double* __restrict__ Yb, const int32_t* __restrict__ vars, double t) {
+  double st[SBM_PROG_MAX_STACK];
+  int sp = 0;
+  for (int pc = 0;; ++pc) {
+    const int op = code[pc];
+    if (op == SBM_OP_END) break;
+    switch (op) {
+      case SBM_OP_VAR: st[sp++] = Yb[vars[code[++pc]]]; break;
+      case SBM_OP_CONST: st[sp++] = consts[code[++pc]]; break;
+      case SBM_OP_TIME: st[sp++] = t; break;
+      case SBM_OP_ADD: --sp; st[sp - 1] += st[sp]; break;
+      case SBM_OP_SUB: --sp; st[sp - 1] -= st[sp]; break;
+      case SBM_OP_MUL: --sp; st[sp - 1] *= st[sp]; break;
+      case SBM_OP_DIV: --sp; st[sp - 1] /= st[sp]; break;
+      case SBM_OP_POW: --sp; st[sp - 1] = pow(st[sp - 1], st[sp]); break;
+      case SBM_OP_POWI: {
+        int n = code[++pc];
+        const bool inv = n < 0;
+        n = inv ? -n : n;
+        double b = st[sp - 1], r = 1.0;
+        while (n) { if (n & 1) r *= b; b *= b; n >>= 1; }
+        st[sp - 1] = inv ? 1.0 / r : r;
+        break;
+      }
+      case SBM_OP_NEG: st[sp - 1] = -st[sp - 1]; break;
+      case SBM_OP_EXP: st[sp - 1] = exp(st[sp - 1]); break;
+      case SBM_OP_LOG: st[sp - 1] = log(st[sp - 1]); break;
+      case SBM_OP_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
+      case SBM_OP_TANH: st[sp - 1] = tanh(st[sp - 1]); break;
+      case SBM_OP_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+      case SBM_OP_COS: st[sp - 1] = cos(st[sp - 1]); break;
+      case SBM_OP_ABS: st[sp - 1] = fabs(st[sp - 1]); break;
+      case SBM_OP_SIGN: st[sp - 1] = st[sp - 1] > 0.0 ? 1.0 : (st[sp - 1] < 0.0 ? -1.0 : 0.0); break;
+      default: return __builtin_nan("");
+    }
+  }
+  return sp == 1 ? st[0] : __builtin_nan("");
+}
 
 // One block (256 threads) per parameter vector.
 // LDS: sims[R], B[G], sde[G], sds[G], dB[G][q] (Jacobian mode), reduction scratch.
@@ -500,7 +551,9 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
   int* s_rnv = s_rv0 + R;                   // [R] its length
   int* s_rvar = s_rnv + R;                  // [R] first variable (the only one of a 'direct' mapping)
   int* s_rsf = s_rvar + R;                  // [R] scale-factor group or -1
-  double* s_dB = (double*)(s_rsf + R);      // 6 R ints = 24 R bytes: 8-byte aligned.  [G][q], then the partial sums [2][G][rpp][q]
+  int* s_rw0 = s_rsf + R;                   // [R + (R & 1)] first dg/dy weight slot of a custom row, -1 for plain rows
+  double* s_w = (double*)(s_rw0 + R + (R & 1));   // [NW] dg/dy_k of the custom rows at this vector's sampled states
+  double* s_dB = s_w + a.NW;                // 8-byte aligned.  [G][q], then the partial sums [2][G][rpp][q]
   __shared__ int s_bad;
 
   if (tid == 0) s_bad = 0;
@@ -508,6 +561,7 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
     s_d[r] = a.row_data[r];
     s_sg[r] = a.row_sigma[r];
     s_rsf[r] = a.row_sf[r];
+    s_rw0[r] = (a.row_w0 && !a.sims_in) ? a.row_w0[r] : -1;
     if (!a.sims_in) {
       const int e = a.row_exp[r], v0 = a.row_var_off[r];
       s_rexp[r] = e;
@@ -539,7 +593,16 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
       s = a.sims_in[(size_t)v * R + r];
     } else {
       const double* Yb = a.Y + (size_t)v * E * a.n_t * a.NV + s_roff[r];
-      if (s_rnv[r] == 1) s = Yb[s_rvar[r]];
+      if (s_rw0[r] >= 0) {
+        // custom observable: value g(y), and dg/dy_k parked in LDS for the Jacobian pass
+        const int32_t* sub = a.prog_sub_off + a.prog_base[a.row_prog[r]];
+        const int32_t* vars = a.row_vars + s_rv0[r];
+        const double tr = a.row_time[r];
+        s = sbm_prog_eval(a.prog_code + sub[0], a.prog_const, Yb, vars, tr);
+        if (a.S)
+          for (int k = 0; k < s_rnv[r]; ++k)
+            s_w[s_rw0[r] + k] = sbm_prog_eval(a.prog_code + sub[1 + k], a.prog_const, Yb, vars, tr);
+      } else if (s_rnv[r] == 1) s = Yb[s_rvar[r]];
       else for (int k = s_rv0[r]; k < s_rv0[r] + s_rnv[r]; ++k) s += Yb[a.row_vars[k]];
     }
     s_sim[r] = s;
@@ -659,13 +722,19 @@ __global__ void __launch_bounds__(256) k_assemble(AssembleArgs a) {
           sc1 = (k1 - k0 == 1) ? a.sens_col[a.inv_m[k0]] : -2;   // the common case: one model parameter per slot
         }
         const double* Sb = a.S + ((size_t)v * E * a.n_t * a.NV + s_roff[r]) * a.NK;
-        if (sc1 >= 0 && s_rnv[r] == 1) {
+        const int w0 = s_rw0[r];
+        if (sc1 >= 0 && s_rnv[r] == 1 && w0 < 0) {
           jm = Sb[(size_t)s_rvar[r] * a.NK + sc1];
         } else if (sc1 != -1) {
           for (int k = k0; k < k1; ++k) {
             const int sc = a.sens_col[a.inv_m[k]];
             if (sc < 0) continue;
-            for (int kk = s_rv0[r]; kk < s_rv0[r] + s_rnv[r]; ++kk) jm += Sb[(size_t)a.row_vars[kk] * a.NK + sc];
+            if (w0 < 0) {
+              for (int kk = s_rv0[r]; kk < s_rv0[r] + s_rnv[r]; ++kk) jm += Sb[(size_t)a.row_vars[kk] * a.NK + sc];
+            } else {   // custom observable: sum_k dg/dy_k * S[var_k][sc]
+              for (int kk = 0; kk < s_rnv[r]; ++kk)
+                jm = fma(s_w[w0 + kk], Sb[(size_t)a.row_vars[s_rv0[r] + kk] * a.NK + sc], jm);
+            }
           }
         }
         jm *= dth;
@@ -806,6 +875,68 @@ extern "C" int sbm_project_load(sbm_model* m, const sbm_project_desc* d, sbm_pro
     if (d->loss_type == SBM_LOSS_LOG_SQUARE && !(d->row_data[r] > 0.0))
       return sbm_fail(SBM_E_ARG, "sbm_project_load: LogSquare loss cannot handle measurements smaller or equal to zero (row %d)", r);
   }
+  // custom observables: every program is checked here, once, so that the interpreter in the kernel can run unchecked
+  const int NPG = d->n_programs;
+  std::vector<int32_t> prog_base((size_t)(NPG > 0 ? NPG : 0) + 1, 0), row_w0((size_t)(R > 0 ? R : 1), -1);
+  int n_weights = 0;
+  if (NPG < 0) return sbm_fail(SBM_E_ARG, "sbm_project_load: n_programs < 0");
+  if (NPG > 0) {
+    if (!d->row_prog || !d->prog_nvars || !d->prog_sub_off || !d->prog_code || !d->row_time || d->n_prog_code <= 0 ||
+        (d->n_prog_const > 0 && !d->prog_const))
+      return sbm_fail(SBM_E_ARG, "sbm_project_load: NULL program table");
+    for (int c = 0; c < NPG; ++c) {
+      if (d->prog_nvars[c] < 0 || d->prog_nvars[c] > 64) return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d lists %d variables", c, d->prog_nvars[c]);
+      prog_base[c + 1] = prog_base[c] + 1 + d->prog_nvars[c];
+    }
+    for (int c = 0; c < NPG; ++c) {
+      for (int sidx = prog_base[c]; sidx < prog_base[c + 1]; ++sidx) {
+        int pc = d->prog_sub_off[sidx], depth = 0;
+        const int end = d->prog_sub_off[sidx + 1];
+        if (pc < 0 || end > d->n_prog_code || pc >= end) return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: bad subprogram bounds", c);
+        bool closed = false;
+        for (; pc < end && !closed; ++pc) {
+          const int op = d->prog_code[pc];
+          switch (op) {
+            case SBM_OP_END: closed = true; break;
+            case SBM_OP_VAR:
+              if (++pc >= end || d->prog_code[pc] < 0 || d->prog_code[pc] >= d->prog_nvars[c])
+                return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: variable operand out of range", c);
+              ++depth; break;
+            case SBM_OP_CONST:
+              if (++pc >= end || d->prog_code[pc] < 0 || d->prog_code[pc] >= d->n_prog_const)
+                return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: constant operand out of range", c);
+              ++depth; break;
+            case SBM_OP_TIME: ++depth; break;
+            case SBM_OP_ADD: case SBM_OP_SUB: case SBM_OP_MUL: case SBM_OP_DIV: case SBM_OP_POW:
+              if (depth < 2) return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: stack underflow", c);
+              --depth; break;
+            case SBM_OP_POWI:
+              if (++pc >= end || d->prog_code[pc] < -64 || d->prog_code[pc] > 64)
+                return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: integer power out of range", c);
+              if (depth < 1) return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: stack underflow", c);
+              break;
+            case SBM_OP_NEG: case SBM_OP_EXP: case SBM_OP_LOG: case SBM_OP_SQRT: case SBM_OP_TANH: case SBM_OP_SIN:
+            case SBM_OP_COS: case SBM_OP_ABS: case SBM_OP_SIGN:
+              if (depth < 1) return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: stack underflow", c);
+              break;
+            default: return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: unknown opcode %d", c, op);
+          }
+          if (depth > SBM_PROG_MAX_STACK) return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d needs a stack deeper than %d", c, SBM_PROG_MAX_STACK);
+        }
+        if (!closed || depth != 1) return sbm_fail(SBM_E_ARG, "sbm_project_load: program %d: subprogram does not leave exactly one value", c);
+      }
+    }
+    for (int r = 0; r < R; ++r) {
+      const int c = d->row_prog[r];
+      if (c >= NPG) return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d program %d of %d", r, c, NPG);
+      if (c < 0) continue;
+      if (d->row_var_off[r + 1] - d->row_var_off[r] != d->prog_nvars[c])
+        return sbm_fail(SBM_E_ARG, "sbm_project_load: row %d lists %d variables, its program %d takes %d", r,
+                        d->row_var_off[r + 1] - d->row_var_off[r], c, d->prog_nvars[c]);
+      row_w0[r] = n_weights;
+      n_weights += d->prog_nvars[c];
+    }
+  }
   for (int k = 0; k < NPR; ++k)
     if (d->prior_idx[k] < 0 || d->prior_idx[k] >= q) return sbm_fail(SBM_E_ARG, "sbm_project_load: prior index");
   for (int k = 0; k < NSP; ++k)
@@ -854,6 +985,17 @@ extern "C" int sbm_project_load(sbm_model* m, const sbm_project_desc* d, sbm_pro
   bad |= upload(p->sfp_sigma, d->sf_prior_sigma, (size_t)NSP, s);
   bad |= upload(p->inv_ptr, inv_ptr.data(), inv_ptr.size(), s);
   bad |= upload(p->inv_m, inv_m.data(), inv_m.size(), s);
+  p->n_programs = NPG;
+  p->n_custom_weights = n_weights;
+  if (NPG > 0) {
+    bad |= upload(p->row_prog, d->row_prog, (size_t)R, s);
+    bad |= upload(p->row_w0, row_w0.data(), (size_t)R, s);
+    bad |= upload(p->prog_base, prog_base.data(), prog_base.size(), s);
+    bad |= upload(p->prog_sub_off, d->prog_sub_off, (size_t)prog_base[NPG] + 1, s);
+    bad |= upload(p->prog_code, d->prog_code, (size_t)d->n_prog_code, s);
+    bad |= upload(p->prog_const, d->prog_const, (size_t)d->n_prog_const, s);
+    bad |= upload(p->row_time, d->row_time, (size_t)R, s);
+  }
   hipError_t e = hipStreamSynchronize(s);  // host vectors go out of scope
   if (bad || e != hipSuccess) {
     sbm_project_unload(p);
@@ -871,6 +1013,8 @@ extern "C" int sbm_project_unload(sbm_project* p) {
   p->inv_ptr.release(); p->inv_m.release(); p->pfixed.release(); p->tgrid.release(); p->row_data.release();
   p->row_sigma.release(); p->prior_mean.release(); p->prior_sigma.release();
   p->sfp_group.release(); p->sfp_mean.release(); p->sfp_sigma.release();
+  p->row_prog.release(); p->row_w0.release(); p->prog_base.release(); p->prog_sub_off.release(); p->prog_code.release();
+  p->prog_const.release(); p->row_time.release();
   p->P.release(); p->Y.release(); p->S.release(); p->sims.release(); p->sf.release();
   p->traj_status.release(); p->traj_steps.release(); p->traj_rej.release(); p->goff.release(); p->glen.release();
   for (int l = 0; l < 2; ++l) { p->Yx[l].release(); p->Sx[l].release(); }
@@ -917,7 +1061,8 @@ static int launch_assemble(const AssembleArgs& g, int V, hipStream_t s, const ch
   const int Gn = g.G > 0 ? g.G : 1;
   const int cw_ = g.q < 256 ? g.q : 256, rpp_ = 256 / cw_;
   const size_t lds = sizeof(double) * ((size_t)2 * g.R + 3 * Gn + 4 + (size_t)Gn * g.q + (size_t)2 * Gn * rpp_ * g.q) +
-                     sizeof(double) * 2 * (size_t)g.R + sizeof(int) * (6 * (size_t)g.R + 2);   // + the staged row tables
+                     sizeof(double) * 2 * (size_t)g.R + sizeof(int) * (7 * (size_t)g.R + 2) +   // + the staged row tables
+                     sizeof(double) * (size_t)g.NW;                                               // + custom-row weights
   if (lds > 160 * 1024) return sbm_fail(SBM_E_ARG, "%s: project too large for the assembly kernel (%zu B of LDS)", who, lds);
   if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_assemble, dim3(V), dim3(256), lds, s, g);
@@ -1003,6 +1148,11 @@ static int project_run(sbm_project* p, const double* Theta, int V, const sbm_int
   g.prior_mean = p->prior_mean.p; g.prior_sigma = p->prior_sigma.p;
   g.sfp_group = p->sfp_group.p; g.sfp_mean = p->sfp_mean.p; g.sfp_sigma = p->sfp_sigma.p; g.inv_ptr = p->inv_ptr.p; g.inv_m = p->inv_m.p;
   g.sens_col = p->sens_col.p;
+  if (p->n_programs > 0) {
+    g.NW = p->n_custom_weights;
+    g.row_prog = p->row_prog.p; g.row_w0 = p->row_w0.p; g.prog_base = p->prog_base.p; g.prog_sub_off = p->prog_sub_off.p;
+    g.prog_code = p->prog_code.p; g.prog_const = p->prog_const.p; g.row_time = p->row_time.p;
+  }
   g.Theta = Theta; g.Y = p->Y.p; g.S = sens ? p->S.p : nullptr;
   g.traj_status = p->traj_status.p; g.traj_steps = p->traj_steps.p;
   g.sims = sims ? sims : p->sims.p; g.Rout = Rout; g.sf = sf; g.norms = norms; g.status = status; g.n_steps = n_steps;

@@ -83,8 +83,9 @@ class Project(object):
         self._n_residuals = None
         self._rows = None
         self._last = {}
-        self.integrator_options = dict(getattr(model, 'integrator_options', {}) or
-                                       dict(method='dopri45', rtol=1e-9, atol=1e-12, max_steps=-50000))
+        # the project's OWN overrides: the model's integrator_options are read at call time (so that options set
+        # on the model after the project was built are inherited), these go on top
+        self.integrator_options = {}
         self.add_experiment(experiments)
         self._project_param_vector = np.zeros((self.n_project_params,))
 
@@ -107,8 +108,14 @@ class Project(object):
                     if v >= self._model.n_vars or v < 0:
                         raise ValueError('Index (%d) has to be smaller than %d' % (v, self._model.n_vars))
             elif mapping_type == 'custom':
-                raise ValueError("'custom' measurement mappings are Python callbacks and cannot run in the "
-                                 "assembly kernel; express the observable as 'direct' or 'sum'")
+                # the reference takes Python callbacks here (:125-128); the kernel takes a compiled expression
+                from .observables import compile_observable
+                gm = getattr(self._model, 'generated', None)
+                names = list(gm.spec.variables) if gm is not None else ['y%d' % i for i in range(self._model.n_vars)]
+                comp = compile_observable(mapping_args, names)
+                self._measurement_to_model_map[measure_name] = {'type': 'custom', 'variables': list(comp['variables']),
+                                                                'program': comp}
+                continue
             else:
                 raise ValueError('Invalid mapping type')
             self._measurement_to_model_map[measure_name] = {'type': mapping_type, 'variables': variables}
@@ -314,7 +321,11 @@ class Project(object):
         loss_type = int(getattr(lf, 'loss_type', 0))
         if loss_type == 1 and len(rows['data']) and np.min(rows['data']) <= 0:
             raise ValueError("LogSquare loss cannot handle measurements smaller or equal to zero")
-        return dict(E=E, q=self._n_project_params, R=len(rows['exp']), G=len(groups), loss_type=loss_type,
+        from .observables import program_tables
+        progs = program_tables(rows['measure'], {nm: m['program'] for nm, m in self._measurement_to_model_map.items()
+                                                 if m['type'] == 'custom' and nm in set(rows['measure'])})
+        return dict(row_time=_as_f64(rows['t_sim']), **progs,
+                    E=E, q=self._n_project_params, R=len(rows['exp']), G=len(groups), loss_type=loss_type,
                     pmap=pmap, pfixed=pfixed, sens_col=sens_col, tgrid_off=tgrid_off, tgrid=_as_f64(tgrid),
                     row_exp=rows['exp'], row_tidx=rows['tidx'], row_var_off=_as_int32(var_off),
                     row_vars=_as_int32(var_list), row_data=rows['data'], row_sigma=sigma,
@@ -343,7 +354,11 @@ class Project(object):
             dp(a['row_data']), dp(a['row_sigma']), ip(a['row_sf']),
             ip(a['prior_idx']), dp(a['prior_mean']), dp(a['prior_sigma']),
             ip(a['sf_prior_group']), dp(a['sf_prior_mean']), dp(a['sf_prior_sigma']),
-            a['reference_compat'], a['loss_type'])
+            a['reference_compat'], a['loss_type'],
+            a['n_programs'], len(a['prog_code']), len(a['prog_const']),
+            ip(a['row_prog']) if a['n_programs'] else ctypes.cast(None, _lib.c_int32_p), ip(a['prog_nvars']),
+            ip(a['prog_sub_off']) if a['n_programs'] else ctypes.cast(None, _lib.c_int32_p), ip(a['prog_code']),
+            dp(a['prog_const']), dp(a['row_time']) if a['n_programs'] else ctypes.cast(None, _lib.c_double_p))
         h = ctypes.c_void_p()
         _lib.check(lib.sbm_project_load(self._model.device_model.handle, ctypes.byref(desc), ctypes.byref(h)),
                    'sbm_project_load')
@@ -545,9 +560,15 @@ class Project(object):
     # ------------------------------------------------------------------
     # device evaluation
     # ------------------------------------------------------------------
-    def _opts(self, **overrides):
-        o = dict(self.integrator_options)
+    def _options(self, **overrides):
+        """Effective integrator options of a call: model defaults < project overrides < call overrides."""
+        o = dict(getattr(self._model, 'integrator_options', None) or {})
+        o.update(self.integrator_options)
         o.update(overrides)
+        return o
+
+    def _opts(self, **overrides):
+        o = self._options(**overrides)
         levels = int(o.pop('extrapolate', 0) or 0)
         fixed = ('rk4', 'rk4_fixed') + _lib.FIXED_STEP_IMPLICIT
         if str(o.get('method', 'dopri45')).lower() in fixed and not o.get('h0', 0) > 0:
@@ -592,8 +613,7 @@ class Project(object):
         (stiff ones) -- the control loops of ``_control.py``; the result then also carries 'stiff' (V,)
         bool.  Every other method is one device call.
         """
-        o = dict(self.integrator_options)
-        o.update(integrator_overrides)
+        o = self._options(**integrator_overrides)
         method = str(o.get('method', 'dopri45')).lower()
         if method not in _control.IMPLICIT_CONTROLLED + _control.AUTO:
             return self._evaluate_once(thetas, jacobian, want, **integrator_overrides)
@@ -616,7 +636,7 @@ class Project(object):
                 return split(self._evaluate_once(t, jacobian, want, method='implicit_midpoint_graded',
                                                  n_steps=int(o.get('n_steps', 0) or 256), step_mult=mult,
                                                  extrapolate=0, rtol=max(1e-2 * rtol, 1e-13),
-                                                 atol=max(1e-2 * atol, 1e-300), max_steps=0, **keep))
+                                                 atol=max(1e-2 * atol, 1e-14), max_steps=0, **keep))   # (Newton tolerances)
             # Romberg on the ASSEMBLED outputs: residuals, scale factors, Jacobian ... are smooth functions of the
             # discrete solution, so they inherit its expansion in h^2
             return _control.controlled_romberg(run, len(idx), compare, rtol, atol,
@@ -700,7 +720,7 @@ class Project(object):
         leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)): one parameter vector leaves the chip
         empty, so the sensitivity kernel takes its small-batch split unless the project's options name a variant.
         Results equal the corresponding row of a batch call to the integration tolerance, not bit for bit."""
-        return {} if 'variant' in self.integrator_options else {'variant': 'small_batch'}
+        return {} if 'variant' in self._options() else {'variant': 'small_batch'}
 
     def residuals(self, project_param_vector):
         """(B*sim - data)/sigma for every measurement row, then prior rows; (m,) array."""

@@ -40,8 +40,10 @@ class GeneratedModel(object):
         self.c_source = emit_c(spec, self.derived)
         self.hip_source = emit_hip(spec, self.derived)
         self.n_vars = spec.n_vars
-        self.param_order = list(spec.params)
-        self.sens_params = list(spec.sens_params)
+        # (a spec read from a plain callable may have renamed parameters that are not identifiers: ingest.py)
+        alias = getattr(spec, 'param_aliases', {})
+        self.param_order = [alias.get(p, p) for p in spec.params]
+        self.sens_params = [alias.get(p, p) for p in spec.sens_params]
         self.n_sens = spec.n_sens
         self._header_path = header_path
         ns = {}
@@ -143,6 +145,24 @@ def make_jit_model(model_fh, output_fh=None, calculate_sensitivities=True, name=
 def generated_model_of(fn):
     """The GeneratedModel behind a generated callable, or None."""
     return getattr(fn, '_sbm_generated', None)
+
+
+def model_from_callables(model, sens_model, n_vars, param_order, name='Model'):
+    """GeneratedModel for a PLAIN right-hand side ``model(y, t, yout, p)`` written in the reference's emitted form
+    (``name = p[i]``, ``name = y[i]``, ``yout[i] = expression``: symbolic/sympy_tools.py:100-111,185-195 of the
+    reference), read from its source -- see ingest.py.  Raises ingest.IngestError (a TypeError) for anything else."""
+    import re
+    from .ingest import spec_from_callables
+    spec = spec_from_callables(model, sens_model, n_vars, param_order,
+                               name=re.sub(r'[^0-9A-Za-z_]', '_', str(name)) or 'Model')
+    gm = _INGESTED.get(id(spec))
+    if gm is None:
+        gm = GeneratedModel(spec)
+        _INGESTED[id(spec)] = gm
+    return gm
+
+
+_INGESTED = {}
 
 
 # ---------------------------------------------------------------------------

@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libsbm_hip.so does not export %s" % name
         assert name in _lib.SIGNATURES, "python binding has no signature for %s" % name
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.sbm_abi_version() == 1
+    assert lib.sbm_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -53,10 +53,10 @@ def test_struct_layouts_match_header(tmp_path):
 #include <stddef.h>
 #include "sbm.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sbm_integrator_opts), offsetof(sbm_integrator_opts, rtol),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sbm_integrator_opts), offsetof(sbm_integrator_opts, rtol),
          offsetof(sbm_integrator_opts, t0), sizeof(sbm_project_desc), offsetof(sbm_project_desc, pmap),
          offsetof(sbm_project_desc, reference_compat), sizeof(sbm_loss_desc), offsetof(sbm_loss_desc, row_data),
-         offsetof(sbm_loss_desc, sf_prior_sigma));
+         offsetof(sbm_loss_desc, sf_prior_sigma), offsetof(sbm_project_desc, row_prog), offsetof(sbm_project_desc, row_time));
   return 0;
 }''')
     exe = str(tmp_path / 'layout')
@@ -65,7 +65,8 @@ int main(void) {
     c = [int(x) for x in subprocess.check_output([exe]).split()]
     py = [ctypes.sizeof(_lib.IntegratorOpts), _lib.IntegratorOpts.rtol.offset, _lib.IntegratorOpts.t0.offset,
           ctypes.sizeof(_lib.ProjectDesc), _lib.ProjectDesc.pmap.offset, _lib.ProjectDesc.reference_compat.offset,
-          ctypes.sizeof(_lib.LossDesc), _lib.LossDesc.row_data.offset, _lib.LossDesc.sf_prior_sigma.offset]
+          ctypes.sizeof(_lib.LossDesc), _lib.LossDesc.row_data.offset, _lib.LossDesc.sf_prior_sigma.offset,
+          _lib.ProjectDesc.row_prog.offset, _lib.ProjectDesc.row_time.offset]
     assert c == py
 
 
@@ -87,11 +88,22 @@ def test_no_cpu_fallback_without_device(zoo):
         m.simulate(rc.SIMPLE_P, rc.SIMPLE_T10)
 
 
-def test_odemodel_rejects_plain_callables():
+def test_odemodel_rejects_callables_it_cannot_compile():
+    """Only straight-line code in the reference's emitted form can be read from source (tests/test_ingest.py);
+    anything else is refused -- there is no SciPy path to fall back on."""
     def f(y, t, yout, p):
-        yout[0] = -y[0]
+        for i in range(1):
+            yout[i] = -p[0] * y[i]
     with pytest.raises(TypeError, match="no CPU fallback"):
-        OdeModel(f, f, 1, ['k'], use_jit=False)
+        OdeModel(f, None, 1, ['k'], use_jit=False)
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        OdeModel(np.negative, None, 1, ['k'], use_jit=False)
+
+    def g(y, t, yout, p):
+        k = p[0]
+        yout[0] = (-k * y[0])
+    m = OdeModel(g, None, 1, ['k'], use_jit=False)       # the emitted form is compiled (nothing is built before use)
+    assert m.n_vars == 1 and m.param_order == ['k'] and m.generated.spec.equations['y0'] is not None
 
 
 def test_odemodel_signature_checks(zoo):
@@ -105,8 +117,11 @@ def test_odemodel_signature_checks(zoo):
     m = OdeModel(gm.model, gm.sens_model, 1, gm.param_order, use_jit=False)
     assert m.n_vars == 1 and m.get_n_vars() == 1 and m.param_order == ['k_deg', 'k_synt']
     assert m.use_jac is True and m._jit_enabled is False and m.model_name == 'Model'
-    # defaults: the explicit pair at the tolerance that keeps parity with LSODA, a step budget with early exit
-    assert m.integrator_options == dict(method='dopri45', rtol=1e-9, atol=1e-12, max_steps=-50000)
+    # defaults: the explicit pair at the size-aware tolerance that meets SURVEY section 8(d) against a tight solution
+    # (model/ode_model.py::default_tolerances), a step budget with early exit
+    assert m.integrator_options == dict(method='dopri45', rtol=1e-9, atol=1e-18, max_steps=-50000)
+    from sysbio_modeling_amd.model.ode_model import default_tolerances
+    assert default_tolerances(40)['rtol'] == 1e-9 and default_tolerances(80)['rtol'] == pytest.approx(2.5e-10)
     o = _lib.make_opts(**m.integrator_options)
     assert (o.method, o.max_steps, o.variant) == (_lib.SBM_DOPRI45, -50000, 0)
 
