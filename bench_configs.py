@@ -347,5 +347,47 @@ def variant_extras(model, dev, theta_p, tg, rk4_steps):
     return ex
 
 
-RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'fit': run_fit}
-ORDER = ['configs1', 'configs3', 'configs4', 'fit']
+# ---------------------------------------------------------------------------
+# the MFMA question: dense Jacobian x S on the matrix cores against the scalar kernels
+# ---------------------------------------------------------------------------
+def run_dense(model, gm, dev, reps=3, cpu=True):
+    """SURVEY.md section 8(d) / BASELINE north_star: "MFMA only if the sensitivity-RHS Jacobian x S product is
+    actually dense enough to pay".  The same DOPRI45 driver, the same ensemble shape (4096 vectors, 16 outputs) on
+    20-state networks whose df/dy has 40 (the cascade), 60, 120, 220 and 400 (dense) non-zeros: the scalar kernels
+    (AUTO: what the library picks) against SBM_VARIANT_MFMA (v_mfma_f64_16x16x4_f64 tiles, cost independent of the
+    sparsity).  No CPU leg: same workload family as the headline."""
+    import torch
+    from sysbio_modeling_amd import _lib, models_zoo
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    from sysbio_modeling_amd.model import OdeModel
+    V = 4096
+    _, P = models_zoo.cascade_ensemble(V, spread=0.3)
+    Pd = torch.from_numpy(P).to(dev)
+    tg = torch.from_numpy(np.concatenate([[0.0], np.linspace(6.25, 100.0, 16)])).to(dev)
+    Y = torch.empty((V, 17, 20), dtype=torch.float64, device=dev)
+    S = torch.empty((V, 17, 20, 40), dtype=torch.float64, device=dev)
+    ns = torch.empty((V,), dtype=torch.int32, device=dev)
+    st = torch.empty((V,), dtype=torch.int32, device=dev)
+    out = {"workload": "20 states / 40 parameters with forward sensitivities (820 ODEs), 4096 vectors, DOPRI45 rtol 1e-9 "
+                       "atol 1e-12, 16 output times; by the number of non-zeros of df/dy"}
+    models = [('cascade20', model)]
+    for dens in (0.1, 0.25, 0.5, 1.0):
+        spec = models_zoo.dense_spec(density=dens)
+        g = GeneratedModel(spec)
+        mm = OdeModel(g.model, g.sens_model, g.n_vars, g.param_order, model_name=spec.name, use_jit=False)
+        mm.enable_jit(model.device_model.ctx)
+        models.append((spec.name, mm))
+    for name, mm in models:
+        row = {"nnz_jy": int(mm.generated.hip_source.split('NNZ_JY = ')[1].split(';')[0])}
+        for label, variant in (('valu', 'auto'), ('mfma', 'mfma')):
+            o = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant=variant)
+            ms = _events(torch, dev, lambda: mm.device_model.sens_dev(Pd, tg, None, o, Y, S, st, ns, None), reps)
+            steps = int(ns.sum().item())
+            row[label] = {"ms": ms, "steps": steps, "steps_per_s": steps / (ms * 1e-3), "failed_vectors": int((st != 0).sum().item())}
+        row["mfma_over_valu_time"] = row['mfma']['ms'] / row['valu']['ms']
+        out[name] = row
+    return out
+
+
+RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'fit': run_fit, 'dense': run_dense}
+ORDER = ['configs1', 'configs3', 'configs4', 'fit', 'dense']

@@ -52,22 +52,33 @@ enum {
    * fixed step resolves.  The pattern belongs to the first step of the step_mult = 1 grid;
    * with step_mult = m every substep is cut into m parts, so that the grids of runs with
    * different step_mult are nested (what the h^2 expansion needs).                           */
-  SBM_IMPLICIT_MIDPOINT_GRADED = 3
+  SBM_IMPLICIT_MIDPOINT_GRADED = 3,
+  /* Stiff systems in ONE call: implicit midpoint with error control inside the kernel.  A coarse solution (steps H)
+   * and a fine one (steps H/2, nested grid) are carried side by side and never mixed; what is written at an output
+   * time is their passive extrapolation (4 fine - coarse)/3 (the symmetric rule's error expands in H^2: fourth
+   * order), and (fine - coarse)/3 there is the error estimate: too large at any output time and the trajectory
+   * starts over with more steps per unit time (at most 12 passes; one restart is the rule).  rtol / atol as for
+   * DOPRI45 (state AND sensitivities, column by column); h0 = coarse step of the first pass (<= 0: span / 256).
+   * The first step is graded as in SBM_IMPLICIT_MIDPOINT_GRADED.  What method='auto' of the Python classes
+   * switches to for vectors DOPRI45 gives up on -- the role of LSODA's own switch to BDF
+   * (model/ode_model.py:122-123).  n_steps counts the coarse steps of the accepted pass (each goes with two fine
+   * steps: three midpoint solves), n_reject those of the abandoned passes. */
+  SBM_IMPLICIT_ADAPTIVE = 4
 };
 
 typedef struct sbm_integrator_opts {
-  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_IMPLICIT_MIDPOINT[_GRADED] */
+  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_IMPLICIT_MIDPOINT[_GRADED] | SBM_IMPLICIT_ADAPTIVE */
   int32_t max_steps; /* per trajectory, accepted + rejected; 0 -> 1000000.  DOPRI45, negative: a budget of
                       * |max_steps| with an early exit (status SBM_MAX_STEPS at once) for a trajectory whose
                       * current step size would need more than four budgets for the remaining time span --
                       * checked every 256 attempts from the 512th on: the explicit method on a stiff system */
-  double rtol;       /* DOPRI45 relative tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
-  double atol;       /* DOPRI45 absolute tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
+  double rtol;       /* DOPRI45, IMPLICIT_ADAPTIVE: relative tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
+  double atol;       /* DOPRI45, IMPLICIT_ADAPTIVE: absolute tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
   double h0;         /* RK4, IMPLICIT_MIDPOINT: step size; DOPRI45: initial step (<=0 -> automatic) */
   double t0;         /* time of the initial condition; output times must be >= t0.
                       * odeint takes t_sim[0] for it (model/ode_model.py:122,167);
                       * Project always integrates from 0 (base_project.py:419)     */
-  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE | _ROW_GROUP | _SMALL_BATCH */
+  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE | _ROW_GROUP | _SMALL_BATCH | _MFMA */
   int32_t step_mult; /* fixed-step methods: every output interval is cut into
                       * step_mult * ceil(dt / h0) equal steps (0 = 1).  Doubling it halves every
                       * step exactly, which is what Richardson extrapolation needs.          */
@@ -99,7 +110,13 @@ enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2,
         * waits for -- while n_traj x chunks <= 1024 (a SIMD each).  The two splits take different step sequences:
         * results agree to the integration tolerance, not bit for bit, which is why AUTO never switches by itself
         * (a batch call's rows do not depend on the size of the batch). */
-       SBM_VARIANT_SMALL_BATCH = 4 };
+       SBM_VARIANT_SMALL_BATCH = 4,
+       /* The product J_y S of the sensitivity right-hand side on the matrix cores (v_mfma_f64_16x16x4_f64 tiles, S kept
+        * in the accumulator layout, J_y handed over as a dense tile image): cost independent of the sparsity of J_y.
+        * Opt-in: on MI355X the f64 matrix rate equals the f64 vector rate, so it pays only for dense Jacobians
+        * (DESIGN.md records the measured crossover).  n_vars <= 64, sensitivity entry points, DOPRI45 / RK4; falls
+        * back to AUTO otherwise. */
+       SBM_VARIANT_MFMA = 5 };
 
 /* per-trajectory status written next to the results (the reference does not
  * check LSODA failures, model/ode_model.py:122,167; non-zero statuses are what
@@ -110,8 +127,9 @@ enum {
   SBM_NON_FINITE = 2,
   SBM_STEP_UNDERFLOW = 3,
   SBM_NEWTON_FAIL = 4,  /* implicit midpoint: Newton did not converge in 12 iterations */
-  SBM_TOL_NOT_REACHED = 5  /* set by the HOST control loop around the implicit integrator (Romberg table over runs
-                              with step_mult = 1, 2, 4, ..., sysbio_modeling_amd/_control.py), never by a kernel */
+  SBM_TOL_NOT_REACHED = 5  /* SBM_IMPLICIT_ADAPTIVE after its last refinement pass, and the HOST control loop around the
+                              fixed-step implicit integrator (sysbio_modeling_amd/_control.py): the finest result is
+                              returned, its error estimate is above the tolerance */
 };
 
 /* ---- context ----------------------------------------------------------- */

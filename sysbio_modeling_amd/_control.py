@@ -27,7 +27,7 @@ import numpy as np
 SBM_OK = 0
 SBM_TOL_NOT_REACHED = 5          # include/sbm.h: host-side status of the control loop
 
-IMPLICIT_CONTROLLED = ('implicit_controlled', 'implicit_auto', 'stiff')
+IMPLICIT_CONTROLLED = ('implicit_romberg',)      # the host loop below; 'implicit_controlled' is the in-kernel control now
 AUTO = ('auto', 'lsoda_like')
 
 
@@ -223,6 +223,6 @@ def with_stiff_fallback(run_explicit, run_controlled, n_vectors):
         for k in out:
             if _is_torch(out[k]) or isinstance(out[k], np.ndarray):
                 _assign(out[k], idx, out2[k])
-        st[idx] = st2
-        steps[idx] += steps2
+        st[idx] = _to_numpy(st2).astype(np.int32)
+        steps[idx] += _to_numpy(steps2).astype(np.int64)
     return out, st, steps, stiff

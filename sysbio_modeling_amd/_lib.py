@@ -18,6 +18,7 @@ SBM_RK4_FIXED = 0
 SBM_DOPRI45 = 1
 SBM_IMPLICIT_MIDPOINT = 2
 SBM_IMPLICIT_MIDPOINT_GRADED = 3
+SBM_IMPLICIT_ADAPTIVE = 4
 STATUS_NAMES = {0: 'ok', 1: 'max_steps', 2: 'non_finite', 3: 'step_underflow', 4: 'newton_fail',
                 5: 'tolerance_not_reached'}
 
@@ -136,9 +137,10 @@ def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+IMPLICIT_ADAPTIVE = ('implicit_adaptive', 'implicit', 'imid_adaptive', 'implicit_controlled', 'implicit_auto', 'stiff')
 IMPLICIT_GRADED = ('implicit_midpoint_graded', 'imid_graded')
 FIXED_STEP_IMPLICIT = ('implicit_midpoint', 'imid', 'midpoint') + IMPLICIT_GRADED
-VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3, 'small_batch': 4}
+VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3, 'small_batch': 4, 'mfma': 5}
 
 
 def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None, t0=0.0,
@@ -151,12 +153,15 @@ def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_st
             m = SBM_DOPRI45
         elif key in ('rk4', 'rk4_fixed'):
             m = SBM_RK4_FIXED
+        elif key in IMPLICIT_ADAPTIVE:
+            m = SBM_IMPLICIT_ADAPTIVE
         elif key in IMPLICIT_GRADED:
             m = SBM_IMPLICIT_MIDPOINT_GRADED
         elif key in FIXED_STEP_IMPLICIT:
             m = SBM_IMPLICIT_MIDPOINT
         else:
-            raise ValueError("unknown integrator %r (use 'dopri45', 'rk4', 'implicit_midpoint' or 'implicit_midpoint_graded')" % method)
+            raise ValueError("unknown integrator %r (use 'dopri45', 'rk4', 'implicit_adaptive', 'implicit_midpoint' or "
+                             "'implicit_midpoint_graded')" % method)
     else:
         m = int(method)
     if m in (SBM_RK4_FIXED, SBM_IMPLICIT_MIDPOINT, SBM_IMPLICIT_MIDPOINT_GRADED) and not h0 > 0.0:

@@ -203,21 +203,22 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
   if (!o) return sbm_fail(SBM_E_ARG, "%s: opts is NULL", who);
   if (o->method == SBM_RK4_FIXED) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: RK4 needs h0 > 0", who);
-  } else if (o->method == SBM_DOPRI45) {
-    if (!(o->rtol > 0.0) || !(o->atol > 0.0)) return sbm_fail(SBM_E_ARG, "%s: DOPRI45 needs rtol, atol > 0", who);
+  } else if (o->method == SBM_DOPRI45 || o->method == SBM_IMPLICIT_ADAPTIVE) {
+    if (!(o->rtol > 0.0) || !(o->atol > 0.0)) return sbm_fail(SBM_E_ARG, "%s: adaptive methods need rtol, atol > 0", who);
   } else if (o->method == SBM_IMPLICIT_MIDPOINT || o->method == SBM_IMPLICIT_MIDPOINT_GRADED) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: implicit midpoint needs h0 > 0", who);
   } else {
     return sbm_fail(SBM_E_ARG, "%s: unknown method %d", who, o->method);
   }
   if (o->step_mult < 0 || o->step_mult > 65536) return sbm_fail(SBM_E_ARG, "%s: step_mult %d", who, o->step_mult);
-  if (o->variant < SBM_VARIANT_AUTO || o->variant > SBM_VARIANT_SMALL_BATCH)
+  if (o->variant < SBM_VARIANT_AUTO || o->variant > SBM_VARIANT_MFMA)
     return sbm_fail(SBM_E_ARG, "%s: unknown kernel variant %d", who, o->variant);
   return 0;
 }
 
 static int check_model_fits(const sbm_model* m, const sbm_integrator_opts& o, const char* who) {
-  if ((o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED) && m->info.n_vars > 64)
+  if ((o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED || o.method == SBM_IMPLICIT_ADAPTIVE) &&
+      m->info.n_vars > 64)
     return sbm_fail(SBM_E_ARG, "%s: the implicit midpoint kernel holds one state variable per lane: n_vars <= 64 "
                     "(model '%s' has %d)", who, m->info.name, m->info.n_vars);
   return 0;

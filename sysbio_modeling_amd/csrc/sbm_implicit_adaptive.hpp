@@ -1,0 +1,390 @@
+// sbm_implicit_adaptive.hpp -- implicit midpoint with error control INSIDE the kernel (SBM_IMPLICIT_ADAPTIVE).
+//
+// The reference never picks an integrator: scipy.integrate.odeint is LSODA, which goes implicit on a stiff system by
+// itself and controls its error (model/ode_model.py:122-123,167-168).  The fixed-step kernel of sbm_integrators.hpp
+// (sbm_imid_kernel) needed a host loop around it for that (whole-ensemble runs with n, 2n, 4n, ... steps combined in a
+// Romberg table: _control.py -- seconds per ensemble).  Here the control sits inside the kernel, one launch:
+//
+//   Two solutions are carried side by side and NEVER mixed: a coarse one (steps of size H) and a fine one (steps
+//   of size H/2 on the nested grid).  The implicit midpoint rule is symmetric, so both have global errors that expand
+//   in H^2, and what is written at an output time is the PASSIVE extrapolation (4 fine - coarse) / 3 (fourth order);
+//   (fine - coarse) / 3 at the output times estimates the global error of the fine solution.  Too large at any output
+//   time: the trajectory starts over with more steps per unit time (the estimate falls as n^-2: n <- n sqrt(est)
+//   with a margin, so one restart is the rule, and a pass that is clearly failing is abandoned at its first bad
+//   output).  Every pass uses ONE step size per output interval -- see below why.
+//
+// Two designs that were built first and measured, and why they are not here:
+//  * Step doubling with local extrapolation (advance with (4 fine - coarse) / 3 after every macro step) is UNSTABLE
+//    on stiff systems: the midpoint rule's amplification factor tends to -1 for h lambda -> -infinity (A- but not
+//    L-stable), two half steps give +1, so the locally extrapolated step multiplies a stiff deviation by
+//    (4 - (-1)) / 3 = 5/3.  Its controller saved the run by keeping h |lambda| = O(1): 275 000 steps per vector on
+//    stiff50 where 4096 suffice.
+//  * Keeping the two solutions apart but choosing the step count per OUTPUT INTERVAL (retry an interval from its
+//    start) works for the state and fails for the sensitivities: every change of the step size leaves a deviation of
+//    the stiff components from the numerical slow manifold, the rule damps it by only 1 - O(1/(h lambda)) per step,
+//    and the estimator then sees an oscillation of fixed size that no refinement of the interval removes (a third of
+//    the stiff50 vectors stalled around the fifth interval).  A uniform grid from t0 excites nothing.
+//
+// The estimate belongs to the SECOND-order fine solution while the FOURTH-order combination is what is returned:
+// global errors e2 = C2 H^2 and e4 = C4 H^4 = (C4 / C2^2) e2^2, so a tolerance tol on the returned values is met with
+// the estimate held at SBM_IMAD_KAPPA sqrt(tol); the constant (it stands for sqrt(C2^2 / C4); 1.0) is calibrated on
+// stiff50 against a tight LSODA solution (tests/golden/stiff50_tight.npz) and checked on the other models of
+// tests/test_gpu_implicit.py.  Error norm as in the explicit kernels:
+// max(RMS over the state, max over the sensitivity columns of the column RMS), every element against
+// atol + rtol |value|.  The first step of a trajectory is graded (13 geometric substeps, as
+// SBM_IMPLICIT_MIDPOINT_GRADED; cut once more in the fine solution): the reference always starts from y = 0, possibly
+// off a fast manifold.
+//
+// Mapping: that of sbm_imid_kernel (lane j = column j of S with all NV rows in registers, lane i = state component i,
+// row lanes evaluate f_i / J_y / J_p by class; sparse LU from emit_implicit.py, distributed for triangular patterns).
+// Registers: the S columns of the solution being advanced and the solver's work vector b, as in the fixed-step
+// kernel; the other solution's columns wait in LDS ([row][lane], 8 NV 64 bytes).  J_p reaches the columns through a compact table
+// (RL_MAXJP values per row, picked by column index) when rows have few parameter entries, through the dense
+// [row][64] table otherwise.
+#pragma once
+
+#ifndef SBM_IMAD_KAPPA
+#define SBM_IMAD_KAPPA 1.0
+#endif
+
+template <class M>
+struct SbmImadShared {
+  static constexpr bool A_SPARSE = (M::RL_MAXJP <= 4);
+  double Y[64];                 // iterate, one component per row lane
+  double G[64];                 // Newton residual, one component per row lane
+  double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
+  double MF[M::IM_NM + 2];      // IM_TRI: reciprocal pivots and scaled entries, written row by row lane
+  double A[A_SPARSE ? (M::NV * M::RL_MAXJP + 2) : (M::NV * 64 + 2)];   // J_p: [row][slot] or [row][column]
+  double ZO[M::NV * 64];        // S of the solution that is NOT being advanced at the moment, [row][lane]
+};
+
+template <class M>
+struct SbmImadStepper {
+  static constexpr int NV = M::NV;
+  using Sh = SbmImadShared<M>;
+  Sh* sh;
+  int lane, chunk, cls;
+  bool has_row;
+  int yidx[M::RL_MAXYS], jyout[M::RL_MAXJY], apos[M::RL_MAXJP], mfpos[M::RL_MAXJY];
+  int rdpos, diagslot;
+  double ps[M::RL_MAXPS];
+  double m[M::IM_NM];
+
+  __device__ __forceinline__ static void fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
+
+  // Newton on the midpoint state of one step of size 2*hh from y: on entry yb = predictor, on exit the midpoint.
+  // Leaves the factors of M = I - hh J_y (m / sh->MF) and J_p (sh->A) of the last iterate for sens().
+  // Returns SBM_OK, SBM_NEWTON_FAIL or SBM_NON_FINITE (wave-uniform).
+  __device__ __forceinline__ int newton(double tm, double hh, double y, double& yb, double nrtol, double natol,
+                                        int& n_iter) {
+    constexpr int MAXIT = 10;
+    for (int it = 0; it < MAXIT; ++it) {
+      ++n_iter;
+      sh->Y[lane] = yb;
+      fence();
+      double ys[M::RL_MAXYS];
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXYS; ++q) ys[q] = sh->Y[yidx[q]];
+      double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJY; ++q) jy[q] = 0.0;
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJP; ++q) jp[q] = 0.0;
+      M::class_dispatch(cls, tm, ys, ps, f, jy, jp);
+      fence();
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJP; ++q) sh->A[apos[q]] = jp[q];
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJY; ++q) sh->JY[jyout[q]] = jy[q];
+      sh->G[lane] = has_row ? (yb - y) - hh * f : 0.0;
+      if constexpr (M::IM_TRI) {
+        double jd = 0.0;
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJY; ++q) jd = sbm_sel(diagslot == q, jy[q], jd);
+        const double rd = sbm_rcp(fma(-hh, jd, 1.0));
+        sh->MF[rdpos] = rd;
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJY; ++q) sh->MF[mfpos[q]] = hh * jy[q] * rd;
+      }
+      fence();
+      double b[NV];
+      if constexpr (M::IM_TRI) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
+        M::im_solve_tri(sh->MF, b);
+        fence();
+      } else {
+        M::im_build(hh, sh->JY, m);
+        M::im_factor(m);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
+        fence();
+        M::im_solve(m, b);
+      }
+      const double d = has_row ? sbm_pick_tree<NV>(b, lane) : 0.0;   // lane i keeps delta_i
+      yb -= d;
+      float r = has_row ? (float)(fabs(d) / fma(nrtol, fabs(yb), natol)) : 0.f;
+      r = sbm_wave_max(sbm_nan_to_inf(r));
+      if (!(r < 3.0e38f)) return SBM_NON_FINITE;
+      if (r <= 1.0f) return SBM_OK;
+    }
+    return SBM_NEWTON_FAIL;
+  }
+
+  // J_p[i][this lane's column]
+  __device__ __forceinline__ double a_of(int i) const {
+    if constexpr (Sh::A_SPARSE) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJP; ++q)
+        a = sbm_sel(M::rl_jpcol(q, i) - 64 * chunk == lane, sh->A[i * M::RL_MAXJP + q], a);
+      return a;
+    } else {
+      return sh->A[i * 64 + lane];
+    }
+  }
+
+  // one midpoint step of the sensitivities with the matrices newton() left: z <- 2 M^-1 (z + hh J_p) - z
+  __device__ __forceinline__ void sens(double hh, double (&z)[NV]) {
+    double b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) b[i] = fma(hh, a_of(i), z[i]);
+    if constexpr (M::IM_TRI) M::im_solve_tri(sh->MF, b);
+    else M::im_solve(m, b);
+    fence();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) z[i] = fma(2.0, b[i], -z[i]);
+  }
+};
+
+template <class M>
+__global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a) {
+  constexpr int NV = M::NV, NK = M::NK;
+  constexpr int NCH = (NK + 63) / 64;
+  using Sh = SbmImadShared<M>;
+  static_assert(NV <= 64, "implicit kernels: one state row per lane");
+  __shared__ Sh sh;
+  if ((int)blockIdx.x >= a.n_traj) return;
+  const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+  const int lane = threadIdx.x;
+  const int chunk = NCH > 1 ? (int)blockIdx.y : 0;
+  const int col = lane + 64 * chunk;
+  for (int i = lane; i < (int)(sizeof(sh.A) / sizeof(double)); i += 64) sh.A[i] = 0.0;
+  for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
+  for (int i = lane; i < M::IM_NM + 2; i += 64) sh.MF[i] = 0.0;
+  sh.Y[lane] = 0.0;
+  sh.G[lane] = 0.0;
+
+  SbmImadStepper<M> st;
+  st.sh = &sh;
+  st.lane = lane;
+  st.chunk = chunk;
+  const bool has_row = lane < NV, has_col = col < NK;
+  st.has_row = has_row;
+  const int row = has_row ? lane : 0;
+  st.cls = has_row ? M::rl_class(row) : -1;
+  const double* P = a.P + (size_t)traj * M::NP;
+  constexpr int ASPARE = (int)(sizeof(sh.A) / sizeof(double)) - 1;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXYS; ++s) st.yidx[s] = M::rl_ys(s, row);
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXPS; ++s) st.ps[s] = P[M::rl_ps(s, row)];
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJY; ++s) st.jyout[s] = has_row ? M::rl_jyout(s, row) : M::NJY + 1;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJP; ++s) {
+    if constexpr (Sh::A_SPARSE) {
+      st.apos[s] = has_row ? row * M::RL_MAXJP + s : ASPARE;
+    } else if constexpr (NCH == 1) {
+      st.apos[s] = has_row ? M::rl_apos(s, row) : ASPARE;
+    } else {
+      const int lc = M::rl_jpcol(s, row) - 64 * chunk;
+      st.apos[s] = (has_row && lc >= 0 && lc < 64) ? row * 64 + lc : ASPARE;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJY; ++s) st.mfpos[s] = (M::IM_TRI && has_row) ? M::im_mfpos(s, row) : M::IM_NM + 1;
+  st.rdpos = (M::IM_TRI && has_row) ? M::im_rstart(row) : M::IM_NM + 1;
+  st.diagslot = (M::IM_TRI && has_row) ? M::im_diagslot(row) : -1;
+#pragma unroll
+  for (int e = 0; e < M::IM_NM; ++e) st.m[e] = 0.0;
+  __syncthreads();
+
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+  const bool with_sens = a.S != nullptr;   // wave-uniform
+
+  double zc[NV];                   // S of the solution being advanced (the other one waits in sh.ZO)
+  double yc = 0.0, yf = 0.0;
+  double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
+  double* St = a.S ? a.S + (size_t)traj * a.n_t * NV * NK : nullptr;
+  const double rtol = a.opts.rtol > 0.0 ? a.opts.rtol : 1e-9, atol = a.opts.atol > 0.0 ? a.opts.atol : 1e-12;
+  const double tau = SBM_IMAD_KAPPA * sqrt(rtol);            // see the header
+  const double tau_abs = tau * (atol / rtol);
+  const double nrtol = 0.03 * rtol;
+  const long long max_steps = a.opts.max_steps > 0 ? a.opts.max_steps : (a.opts.max_steps < 0 ? -(long long)a.opts.max_steps : 4000000LL);
+  constexpr int GRADE = 12;
+  constexpr int MAXPASS = 12;
+  int status = SBM_OK, n_newton = 0;
+  long long n_acc = 0, n_rej = 0;
+  const double t_span = glen > 0 ? tg[glen - 1] - a.opts.t0 : 0.0;
+  // coarse steps per unit time of the first pass
+  double density = a.opts.h0 > 0.0 ? 1.0 / a.opts.h0 : 256.0 / (t_span > 0.0 ? t_span : 1.0);
+
+  bool done = false, complete = false;
+  for (int pass = 0; pass < MAXPASS && !done; ++pass) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { zc[i] = (a.s0 && has_col) ? a.s0[i * NK + col] : 0.0; sh.ZO[i * 64 + lane] = zc[i]; }
+    yc = (a.y0 && has_row) ? a.y0[lane] : 0.0;
+    yf = yc;
+    double t = a.opts.t0;
+    double colmax = 0.0;          // largest |S| entry of this lane's column so far (both solutions agree on its size)
+    float err_max = 0.f;
+    int rc = SBM_OK;
+    long long n_pass = 0;
+    bool first_step = true, abandoned = false;
+    double dyc = 0.0, dyf = 0.0, H_prev = 0.0;    // previous increments: Newton predictors
+    int io = 0;
+    for (; io < glen && rc == SBM_OK && !abandoned; ++io) {
+      const double target = tg[io];
+      const double dt = target - t;
+      if (dt > 0.0) {
+        const double nd = ceil(dt * density - 1e-9);
+        const int n = nd < 1.0 ? 1 : (nd > 2.0e9 ? 2000000000 : (int)nd);
+        if (n_acc + n_rej + n_pass + n > max_steps) { rc = SBM_MAX_STEPS; break; }
+        const double H = dt / n;
+        const float ymax = sbm_wave_max(has_row ? (float)fabs(yf) : 0.f);
+        const double natol = fmax(0.03 * atol, 4.0e-16 * (double)ymax);
+        const double sc_h = H_prev > 0.0 ? H / H_prev : 0.0;
+        dyc *= sc_h;
+        dyf *= sc_h;
+        H_prev = H;
+        for (int s = 0; s < n && rc == SBM_OK; ++s) {
+          const double ts = fma((double)s, H, t);
+          // The coarse solution takes this step in one piece, the fine one in two; the very first step of the
+          // trajectory is graded (pieces H 2^-GRADE, 2^-GRADE, 2^-(GRADE-1), ..., 1/2, each cut once more in the fine
+          // solution: nested grids).  ONE copy of the step code serves all of it, working on (yc, zc): the two
+          // solutions trade places after each phase (a register swap, ~6 NV moves per step against ~20 NV of solver
+          // arithmetic), the waiting one parked in LDS.  Two inlined copies of Newton + solve, a third NV-row
+          // array to work in, or both solutions in registers overflow the register file (measured: 999, 380 and 262
+          // scratch instructions).
+#pragma unroll 1
+          for (int phase = 0; phase < 2; ++phase) {
+            const bool fine = phase == 1;
+            if (rc == SBM_OK) {
+              const double ystart = yc;
+              double dy_pred = fine ? 0.5 * dyf : dyc;
+              const int parts = fine ? 2 : 1;
+              const int nops = first_step ? (GRADE + 1) * parts : parts;
+              double tt = ts;
+#pragma unroll 1
+              for (int k = 0; k < nops && rc == SBM_OK; ++k) {
+                double h = H / parts;
+                if (first_step) {
+                  const int gj = k / parts;
+                  h = ldexp(H, -(gj == 0 ? GRADE : GRADE - gj + 1)) / parts;
+                  dy_pred = 0.0;
+                }
+                const double y_before = yc;
+                double yb = fma(0.5, dy_pred, yc);
+                rc = st.newton(tt + 0.5 * h, 0.5 * h, yc, yb, nrtol, natol, n_newton);
+                if (rc == SBM_OK) {
+                  yc = fma(2.0, yb, -yc);
+                  if (with_sens) st.sens(0.5 * h, zc);
+                }
+                dy_pred = yc - y_before;      // the second half of a fine step starts from the first half's increment
+                tt += h;
+              }
+              if (fine) dyf = yc - ystart; else dyc = yc - ystart;
+            }
+            // trade places: (yc, zc) <-> (yf, sh.ZO); after the second phase everything is back under its own name
+            if (with_sens) {
+#pragma unroll
+              for (int i = 0; i < NV; ++i) { const double tmp = sh.ZO[i * 64 + lane]; sh.ZO[i * 64 + lane] = zc[i]; zc[i] = tmp; }
+            }
+            { const double tmp = yc; yc = yf; yf = tmp; }
+          }
+          first_step = false;
+        }
+        n_pass += n;
+        t = target;
+      }
+      if (rc != SBM_OK) break;
+      // (fine - coarse) / 3: the global error of the fine solution at this output time
+      float cs = 0.f;
+      if (with_sens) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) colmax = fmax(colmax, fabs(zc[i]));
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const double zfi = sh.ZO[i * 64 + lane];
+          const double e = (zfi - zc[i]) * (1.0 / 3.0);
+          // entries below 1e-6 of their column's largest are judged against that (SURVEY.md section 8(d)'s floor)
+          const float r = (float)e * __builtin_amdgcn_rcpf((float)fma(tau, fmax(fabs(zfi), 1e-6 * colmax), tau_abs));
+          cs = fmaf(r, r, cs);
+        }
+      }
+      const double ey = (yf - yc) * (1.0 / 3.0);
+      const float ymax_now = sbm_wave_max(has_row ? (float)fabs(yf) : 0.f);
+      const float ry = has_row ? (float)ey * __builtin_amdgcn_rcpf((float)fma(tau, fmax(fabs(yf), 1e-6 * (double)ymax_now), tau_abs)) : 0.f;
+      const float xs = sbm_wave_sumf(sbm_nan_to_inf(ry * ry));
+      const float mx = sbm_wave_max(has_col ? sbm_nan_to_inf(cs) : 0.f);
+      const float err = sqrtf(fmaxf(mx, xs) * (1.0f / NV));
+      if (!(err < 3.0e38f)) { rc = SBM_NON_FINITE; break; }
+      err_max = fmaxf(err_max, err);
+      // passive extrapolation, for the output only
+      if (Yt && has_row && chunk == 0) Yt[(size_t)io * NV + lane] = fma(yf - yc, 1.0 / 3.0, yf);
+      if (St && has_col) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const double zfi = sh.ZO[i * 64 + lane];
+          St[((size_t)io * NV + i) * NK + col] = fma(zfi - zc[i], 1.0 / 3.0, zfi);
+        }
+      }
+      if (err_max > 4.0f && pass + 1 < MAXPASS) abandoned = true;    // clearly not good enough: do not finish the pass
+    }
+    complete = rc == SBM_OK && !abandoned;
+    if (complete && err_max <= 1.0f) {
+      n_acc += n_pass;
+      done = true;
+    } else if (rc == SBM_MAX_STEPS) {
+      n_rej += n_pass;
+      status = SBM_MAX_STEPS;
+      break;
+    } else {
+      n_rej += n_pass;
+      double grow = 4.0;                                     // Newton failure / non-finite values: a much finer grid
+      if (rc == SBM_OK) grow = fmin(16.0, fmax(1.5, 1.25 * sqrt((double)err_max / 0.5)));
+      density *= grow;
+      if (pass + 1 == MAXPASS) status = rc != SBM_OK ? rc : SBM_TOL_NOT_REACHED;
+    }
+  }
+  if (!done && status == SBM_OK) status = SBM_TOL_NOT_REACHED;
+  if (!done && !(complete && status == SBM_TOL_NOT_REACHED)) {
+    // a failed trajectory reports NaN rows (the last pass may have written a part of them); one that only missed
+    // the tolerance keeps its finest result, as the host loop does (status SBM_TOL_NOT_REACHED)
+    for (int io = 0; io < glen; ++io) {
+      if (Yt && has_row && chunk == 0) Yt[(size_t)io * NV + lane] = __builtin_nan("");
+      if (St && has_col) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + col] = __builtin_nan("");
+      }
+    }
+  }
+  if (lane == 0) {
+    const int na = (int)(n_acc > 2000000000LL ? 2000000000LL : n_acc), nr = (int)(n_rej > 2000000000LL ? 2000000000LL : n_rej);
+    // chunks of a trajectory control their steps separately (each carries a copy of the state next to its own
+    // columns): worst status, most steps
+    if constexpr (NCH > 1) {
+      if (a.status) atomicMax(a.status + traj, status);
+      if (a.n_steps) atomicMax(a.n_steps + traj, na);
+      if (a.n_reject) atomicMax(a.n_reject + traj, nr);
+    } else {
+      if (a.status) a.status[traj] = status;
+      if (a.n_steps) a.n_steps[traj] = na;
+      if (a.n_reject) a.n_reject[traj] = nr;
+    }
+  }
+  (void)n_newton;
+}

@@ -1598,6 +1598,9 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   }
 }
 
+#include "sbm_implicit_adaptive.hpp"
+#include "sbm_sens_mfma.hpp"
+
 // ---------------------------------------------------------------------------
 // host-side launcher used by sbm_plugin_main.hip
 // ---------------------------------------------------------------------------
@@ -1608,6 +1611,22 @@ template <class M>
 static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t stream) {
   const sbm_kernel_args a = *args;
   if (a.n_traj <= 0) return (int)hipSuccess;
+  if (a.opts.method == SBM_IMPLICIT_ADAPTIVE) {
+    if constexpr (M::NV <= 64) {
+      const int nch = a.S ? (M::NK + 63) / 64 : 1;
+      if (nch > 1) {     // chunks combine status / counts with atomicMax
+        hipError_t e = hipSuccess;
+        if (a.status) e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e == hipSuccess && a.n_steps) e = hipMemsetAsync(a.n_steps, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e == hipSuccess && a.n_reject) e = hipMemsetAsync(a.n_reject, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL((sbm_imid_adaptive_kernel<M>), dim3(a.n_traj, nch), dim3(64), 0, stream, a);
+      return (int)hipGetLastError();
+    } else {
+      return (int)hipErrorInvalidConfiguration;
+    }
+  }
   if (a.opts.method == SBM_IMPLICIT_MIDPOINT || a.opts.method == SBM_IMPLICIT_MIDPOINT_GRADED) {
     // one trajectory per wave for both kinds (state only: S == NULL skips the column work)
     if constexpr (M::NV <= 64) {
@@ -1617,6 +1636,30 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
       return (int)hipGetLastError();
     } else {
       return (int)hipErrorInvalidConfiguration;   // needs one row per lane
+    }
+  }
+  // J_y S on the matrix cores (sbm_sens_mfma.hpp) costs the same whatever the sparsity of J_y; the scalar kernels cost
+  // 2 FMAs per non-zero and column.  Measured on 20-state networks, 4096 vectors, DOPRI45 (bench.py "dense",
+  // profiles/r02): 40 non-zeros (cascade20) 5.2 ms scalar / 27 ms MFMA at twice the steps; 120: 8.9 / 14.9; 220: 26.7 /
+  // 16.8; 400 (dense): 65.0 / 21.7 -- the matrix cores win from about 45 % density.  AUTO takes them from there
+  // (a static property of the model: a given model always runs the same kernel); SBM_VARIANT_MFMA forces them.
+  constexpr bool kMfmaPays = M::NV >= 16 && M::NV <= 64 && (long long)M::NNZ_JY * 100 >= 45LL * M::NV * M::NV;
+  if (kind == SBM_KIND_SENS && (a.opts.variant == SBM_VARIANT_MFMA ||
+                                (kMfmaPays && (a.opts.variant == SBM_VARIANT_AUTO || a.opts.variant == SBM_VARIANT_SMALL_BATCH)))) {
+    // models beyond one state row per lane fall through to the scalar kernels
+    if constexpr (M::NV <= 64) {
+      constexpr int nch = SbmMfmaPlan<M>::NCH;
+      if (nch > 1) {
+        hipError_t e = hipSuccess;
+        if (a.status) e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e == hipSuccess && a.n_steps) e = hipMemsetAsync(a.n_steps, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e == hipSuccess && a.n_reject) e = hipMemsetAsync(a.n_reject, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e != hipSuccess) return (int)e;
+      }
+      dim3 grid(a.n_traj, nch), block(64);
+      if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_mfma_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((sbm_sens_mfma_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
+      return (int)hipGetLastError();
     }
   }
   if (kind == SBM_KIND_SENS) {
@@ -1632,12 +1675,13 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     // it is not instantiated beyond 4096 sensitivity entries, and opts.variant becomes a no-op for that model.
     constexpr bool kPerWaveBuilt = !(kRowGroupOk && M::NV * (M::NK + 1) > 4096);
     const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
-                         ((a.opts.variant == SBM_VARIANT_AUTO || a.opts.variant == SBM_VARIANT_SMALL_BATCH) && kRowLanePays);
+                         ((a.opts.variant == SBM_VARIANT_AUTO || a.opts.variant == SBM_VARIANT_SMALL_BATCH ||
+                           a.opts.variant == SBM_VARIANT_MFMA) && kRowLanePays);
     // row-group kernel: the row-lane kernel with the rows of a column split over several lanes,
     // when the emitter found a split that cuts the elements per lane (M::RG_OK)
     if constexpr (kRowGroupOk) {
       if (a.opts.variant == SBM_VARIANT_ROW_GROUP || a.opts.variant == SBM_VARIANT_AUTO ||
-          a.opts.variant == SBM_VARIANT_SMALL_BATCH || !kPerWaveBuilt) {
+          a.opts.variant == SBM_VARIANT_SMALL_BATCH || a.opts.variant == SBM_VARIANT_MFMA || !kPerWaveBuilt) {
         // Two splits of the same form (emit_rowgroup.py): RG0 for throughput; RG1 -- more, smaller column chunks,
         // fewer elements per lane -- while its wavefronts still find an empty SIMD each (1024 of them): a single
         // parameter vector, a serial optimiser's call, is latency-bound and extra wavefronts are free.

@@ -105,6 +105,32 @@ def cascade_ensemble(n_vectors=4096, n=CASCADE_N, seed=20261003, spread=0.5):
     return theta, np.exp(theta)
 
 
+def dense_spec(n=CASCADE_N, density=1.0, name=None, seed=11):
+    """The DENSE-coupled variant of the 20-state model ("a dense variant for MFMA
+    evaluation"): every species is produced at a rate that saturates in a weighted sum over other species,
+
+        x_i' = k_i u_i / (1 + u_i) - d_i x_i,    u_i = 1/10 + sum_o w_o x_{(i + o) mod n},
+
+    with fixed literal weights w_o in [0.2, 1) on a set of offsets o of the given density (a circulant coupling: the
+    same kinetic form in every row, so the row lanes evaluate ONE class, as for the cascade) and a basal input so that
+    the network starts from y = 0.  Parameters k_0.., d_0.. as in the cascade (40 sensitivity columns at n = 20):
+    df/dy has 1 + density (n - 1) non-zeros per row -- 400 in all at density 1 against the cascade's 40."""
+    rng = np.random.default_rng(seed)
+    xs = [Symbol('x%d' % i) for i in range(n)]
+    ks = [Symbol('k%d' % i) for i in range(n)]
+    ds = [Symbol('d%d' % i) for i in range(n)]
+    m = max(1, int(round(density * (n - 1))))
+    offsets = sorted(int(o) for o in rng.choice(np.arange(1, n), size=m, replace=False))
+    eq = OrderedDict()
+    for i in range(n):
+        u = sympy.Rational(1, 10)
+        for o in offsets:
+            u = u + sympy.Rational(1, 2) * xs[(i + o) % n]
+        eq['x%d' % i] = ks[i] * u / (1 + u) - ds[i] * xs[i]
+    return ModelSpec(name=name or ('dense%d' % n if density >= 1.0 else 'dense%d_%02d' % (n, int(round(100 * density)))),
+                     variables=[str(x) for x in xs], params=[str(k) for k in ks] + [str(d) for d in ds], equations=eq)
+
+
 CASCADE_T_END = 100.0
 CASCADE_MEASURE_TIMES = np.linspace(6.25, 100.0, 16)
 CASCADE_MEASURED_SPECIES = (4, 9, 14, 19)

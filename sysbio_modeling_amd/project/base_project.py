@@ -646,10 +646,16 @@ class Project(object):
             stiff = np.ones(V, dtype=bool)
         else:
             budget = abs(int(o.get('max_steps') or 0)) or 50000
+            def implicit(idx):
+                # one device call: the implicit integrator with in-kernel error control (SBM_IMPLICIT_ADAPTIVE)
+                t = th[torch.as_tensor(idx, device=th.device, dtype=torch.long)]
+                return split(self._evaluate_once(t, jacobian, want, method='implicit_adaptive', rtol=rtol,
+                                                 atol=max(atol, 1e-3 * rtol),     # (see OdeModel._run_auto)
+                                                 extrapolate=0, max_steps=0, **keep)) + (None,)
             out, st, steps, stiff = _control.with_stiff_fallback(
                 lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=-budget,
                                                   rtol=rtol, atol=atol, extrapolate=0, **keep)),
-                controlled if self._model.n_vars <= 64 else None, V)
+                implicit if self._model.n_vars <= 64 else None, V)
         out['status'] = torch.as_tensor(st, dtype=torch.int32, device=th.device)
         out['n_steps'] = torch.as_tensor(np.minimum(steps, 2 ** 31 - 1), dtype=torch.int32, device=th.device)
         out['stiff'] = torch.as_tensor(stiff, device=th.device)

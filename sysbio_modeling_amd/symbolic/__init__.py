@@ -35,10 +35,15 @@ class GeneratedModel(object):
     def __init__(self, spec: ModelSpec, header_path=None):
         self.spec = spec
         self.name = spec.name
-        self.derived = Derived(spec)
-        self.python_source = emit_python(spec, self.derived)
-        self.c_source = emit_c(spec, self.derived)
-        self.hip_source = emit_hip(spec, self.derived)
+        self._derived = None
+        cached = self._load_sources()
+        if cached is None:
+            self.python_source = emit_python(spec, self.derived)
+            self.c_source = emit_c(spec, self.derived)
+            self.hip_source = emit_hip(spec, self.derived)
+            self._save_sources()
+        else:
+            self.python_source, self.c_source, self.hip_source = cached
         self.n_vars = spec.n_vars
         # (a spec read from a plain callable may have renamed parameters that are not identifiers: ingest.py)
         alias = getattr(spec, 'param_aliases', {})
@@ -55,6 +60,54 @@ class GeneratedModel(object):
         self.sens_model._sbm_generated = self
         self._plugin = None
         self._c_lib = None
+
+    # -- derivation cache -------------------------------------------------------------------------------------
+    # Deriving and printing a large model costs minutes of SymPy (a densely coupled 20-state network: 3.5 min);
+    # the three generated texts are kept under _build/gen/, keyed by the model's equations and the emitters' own
+    # sources, so that a second process (a test, the benchmark, a rank of a multi-GPU job) starts in milliseconds.
+    @property
+    def derived(self):
+        if self._derived is None:
+            self._derived = Derived(self.spec)
+        return self._derived
+
+    def _cache_path(self):
+        import hashlib
+        from .. import build
+        h = hashlib.sha1()
+        sp = self.spec
+        h.update(repr((sp.name, list(sp.variables), list(sp.params), list(sp.fixed),
+                       [(k, str(v)) for k, v in sp.equations.items()],
+                       sorted(getattr(sp, 'param_aliases', {}).items()))).encode())
+        here = os.path.dirname(os.path.abspath(__file__))
+        for fn in sorted(os.listdir(here)):
+            if fn.endswith('.py'):
+                with open(os.path.join(here, fn), 'rb') as fh:
+                    h.update(fh.read())
+        import re
+        return os.path.join(build.GEN_DIR, 'src_%s_%s.json' % (re.sub(r'[^0-9A-Za-z_]', '_', sp.name), h.hexdigest()[:16]))
+
+    def _load_sources(self):
+        import json
+        try:
+            with open(self._cache_path()) as fh:
+                d = json.load(fh)
+            return d['python'], d['c'], d['hip']
+        except (OSError, ValueError, KeyError):
+            return None
+
+    def _save_sources(self):
+        import json
+        from .. import build
+        try:
+            os.makedirs(build.GEN_DIR, exist_ok=True)
+            path = self._cache_path()
+            tmp = '%s.%d.tmp' % (path, os.getpid())
+            with open(tmp, 'w') as fh:
+                json.dump({'python': self.python_source, 'c': self.c_source, 'hip': self.hip_source}, fh)
+            os.replace(tmp, path)
+        except OSError:
+            pass
 
     # -- analytic ODE Jacobians (the reference's model_jac / sens_model_jac, Dfun of LSODA) -----------------
     def _jacobian_callables(self):

@@ -148,6 +148,30 @@ class Derived:
         self.jp_rows = [[] for _ in range(spec.n_vars)]
         for e, (r, c, _) in enumerate(jp):
             self.jp_rows[r].append((e, c))
+        self._order_slots_by_structure()
+
+    def _order_slots_by_structure(self):
+        """The row-lane class finder (emit_rowlane.find_classes) compares the expression bundles of rows slot by slot,
+        and the slots of a row are its J_y entries in COLUMN order: two rows with the same kinetics but their
+        entries at different column positions (a densely coupled network: the diagonal entry is the i-th of row i)
+        count as different classes.  Sorting a row's entries by expression structure first (symbols blanked), cyclic
+        column offset second, makes such rows line up.  Applied only when it lowers the number of classes: the slot
+        order of every model where column order already works (the cascades, the reference fixtures) stays as it
+        was."""
+        from . import emit_rowlane
+        n = self.spec.n_vars
+        if n < 3:
+            return
+        names = set(self.spec.variables) | set(self.spec.params)
+        blank = {Symbol(nm): Symbol('_') for nm in names}
+        before = len(emit_rowlane.find_classes(self.spec, self)[0])
+        if before <= 1:
+            return
+        old = [list(r) for r in self.jy_rows]
+        self.jy_rows = [sorted(r, key=lambda ec, i=i: (sympy.srepr(self.jy_c[ec[0]].xreplace(blank)), (ec[1] - i) % n))
+                        for i, r in enumerate(old)]
+        if len(emit_rowlane.find_classes(self.spec, self)[0]) >= before:
+            self.jy_rows = old
 
 
 class _ExprPrinter(C99CodePrinter):

@@ -82,9 +82,12 @@ def emit_rowlane_tables(spec, d, printer_factory):
             for s in range(max_jp)]
     # the column alone (-1: unused slot), for kernels that cut the columns into chunks (any number of columns)
     jpc_t = [[(d.jp_rows[i][s][1] if s < len(d.jp_rows[i]) else -1) for i in range(n)] for s in range(max_jp)]
+    # the column of each J_y slot (-1: unused), for the kernel that hands J_y to the matrix cores as a dense tile
+    jyc_t = [[(d.jy_rows[i][s][1] if s < len(d.jy_rows[i]) else -1) for i in range(n)] for s in range(max_jy)]
     L = ["// row-lane tables: [slot][row]",
          "__constant__ short %s_CLASS[%d] = {%s};" % (tag, n, ", ".join(str(r['cls']) for r in row_info)),
-         table("YS", ys_t), table("PS", ps_t), table("JYOUT", jy_t), table("APOS", jp_t), table("JPCOL", jpc_t), ""]
+         table("YS", ys_t), table("PS", ps_t), table("JYOUT", jy_t), table("APOS", jp_t), table("JPCOL", jpc_t),
+         table("JYCOL", jyc_t), ""]
     meta = dict(classes=classes, max_ys=max_ys, max_ps=max_ps, max_jy=max_jy, max_jp=max_jp)
     return L, meta
 
@@ -106,6 +109,7 @@ def emit_rowlane_members(spec, d, meta, make_printer):
          "  __device__ __forceinline__ static int rl_jyout(int slot, int row) { return SBM_RL_JYOUT[slot * NV + row]; }",
          "  __device__ __forceinline__ static int rl_apos(int slot, int row) { return SBM_RL_APOS[slot * NV + row]; }",
          "  __device__ __forceinline__ static int rl_jpcol(int slot, int row) { return SBM_RL_JPCOL[slot * NV + row]; }",
+         "  __device__ __forceinline__ static int rl_jycol(int slot, int row) { return SBM_RL_JYCOL[slot * NV + row]; }",
          "  // one class body per distinct kinetic form; lane = row, operands per lane",
          "  __device__ __forceinline__ static void class_dispatch(int cls, double t, const double (&ys)[RL_MAXYS],",
          "                                                        const double (&ps)[RL_MAXPS], double& f,",

@@ -58,3 +58,72 @@ def test_two_ranks_equal_one_process(tmp_path):
     proj, thetas = _build_project()
     single = proj.evaluate_batch(thetas)['norms']
     assert np.array_equal(a, single)
+
+
+# ---------------------------------------------------------------------------
+# two REAL RCCL ranks, one per device (skipped on a one-GPU box; the driver's multi-GPU run has the devices)
+# ---------------------------------------------------------------------------
+def _device_count():
+    import torch
+    return torch.cuda.device_count()       # (counting devices does not initialise the GPU)
+
+
+def _rccl_worker(rank, world, port, tmpdir):
+    import ctypes
+    import torch
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOCAL_RANK'] = str(rank)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    try:
+        from sysbio_modeling_amd import _lib
+        from sysbio_modeling_amd.distributed import evaluate_sharded, project_norms_evaluator
+        # (1) the Python host's route: torch.distributed over RCCL
+        proj, thetas = _build_project()
+        norms, (lo, hi) = evaluate_sharded(project_norms_evaluator(proj), thetas, device=dev)
+        np.save(os.path.join(tmpdir, 'rccl_norms_%d.npy' % rank), norms.cpu().numpy())
+        # (2) the C ABI's route: sbm_allgather_norms on a communicator the host creates through RCCL's C API; the
+        # unique id travels over the process group's store
+        rccl = ctypes.CDLL('librccl.so.1')
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [('internal', ctypes.c_char * 128)]
+        uid = UniqueId()
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+            store.set('sbm_uid', bytes(uid))
+        else:
+            ctypes.memmove(ctypes.byref(uid), store.get('sbm_uid'), 128)
+        comm = ctypes.c_void_p()
+        rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        assert rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank) == 0
+        try:
+            ctx = proj._model.device_model.ctx
+            n = 1000
+            send = (torch.arange(n, dtype=torch.float64, device=dev) + 10000.0 * rank) * 0.5
+            recv = torch.full((world * n,), -1.0, dtype=torch.float64, device=dev)
+            _lib.check(ctx.lib.sbm_allgather_norms(ctx.handle, comm, _lib.dev_ptr(send), n, _lib.dev_ptr(recv)),
+                       'sbm_allgather_norms')
+            ctx.synchronize()
+            torch.cuda.synchronize(dev)
+            want = torch.cat([(torch.arange(n, dtype=torch.float64, device=dev) + 10000.0 * r) * 0.5 for r in range(world)])
+            assert torch.equal(recv, want)
+        finally:
+            rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            rccl.ncclCommDestroy(comm)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_one_per_device(tmp_path):
+    port = _free_port()
+    mp.spawn(_rccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(tmp_path / ('rccl_norms_%d.npy' % r)) for r in range(2))
+    assert np.array_equal(a, b) and a.shape == (37,)
+    proj, thetas = _build_project()
+    assert np.array_equal(a, proj.evaluate_batch(thetas)['norms'])

@@ -229,7 +229,7 @@ def test_c_abi_device_pointers_and_determinism(gpu_models):
     S = torch.full((V, nt, 20, 40), float('nan'), dtype=torch.float64, device='cuda')
     st = torch.full((V,), -1, dtype=torch.int32, device='cuda')
     ns = torch.zeros_like(st)
-    opts = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+    opts = _lib.make_opts(**{k: m.integrator_options[k] for k in ('method', 'rtol', 'atol')})   # the model's defaults
     dm.sens_dev(Pd, td, None, opts, Y, S, st, ns, None)
     torch.cuda.synchronize()
     assert int((st != 0).sum()) == 0 and int(ns.min()) > 50 and bool(torch.isfinite(S).all())
@@ -803,7 +803,8 @@ def test_large_batch_indexing(gpu_models):
     S = torch.full((V, 17, 20, 40), float('nan'), dtype=torch.float64, device='cuda')
     st = torch.empty(V, dtype=torch.int32, device='cuda')
     ns = torch.empty(V, dtype=torch.int32, device='cuda')
-    dm.sens_dev(Pd, td, None, _lib.make_opts(t0=0.0), Y, S, st, ns, None)
+    dm.sens_dev(Pd, td, None, _lib.make_opts(t0=0.0, **{k: m.integrator_options[k] for k in ('method', 'rtol', 'atol')}),
+                Y, S, st, ns, None)
     torch.cuda.synchronize()
     assert int((st != 0).sum()) == 0 and bool(torch.isfinite(S).all())
     pick = [0, 1, 4095, 4096, 8191, 12345, V - 1]

@@ -133,27 +133,35 @@ def test_config3_project_rows_128_vectors(gpu_models):
                        {k: (v['type'], v['variables'][0]) for k, v in proj._measurement_to_model_map.items()},
                        sf_groups=['s%d' % v for v in models_zoo.CASCADE_MEASURED_SPECIES])
     a = proj.descriptor_arrays()
-    worst = dict(residuals=0.0, jacobian=0.0, sf=0.0, model_jacobian=0.0)
+    keys = ('residuals', 'jacobian', 'sf', 'model_jacobian')
+
+    def errors(v, tight):
+        po.tight = tight
+        ref, sims, B = po.residuals(thetas[v], return_parts=True)
+        Jm = po.model_jacobian(thetas[v])
+        want = dict(residuals=ref, jacobian=po.calc_project_jacobian(thetas[v]), sf=B, model_jacobian=Jm)
+        tau_s, tau_Jm = (tight_taus(a, sims, Jm) if tight else lsoda_taus(a, thetas[v], sims, Jm))
+        t = project_tolerances(a, sims, B, tau_s, Jm, tau_Jm)
+        return {k: tol_ratio(out[k][v], want[k], t[k]) for k in keys}, want, t
+    worst = dict.fromkeys(keys, 0.0)
+    over = []
     for v in range(len(thetas)):
-        ref, sims, B = po.residuals(thetas[v], return_parts=True)
-        Jm = po.model_jacobian(thetas[v])
-        Jref = po.calc_project_jacobian(thetas[v])
-        tau_s, tau_Jm = lsoda_taus(a, thetas[v], sims, Jm)
-        t = project_tolerances(a, sims, B, tau_s, Jm, tau_Jm)
-        for key, got, want in (('residuals', out['residuals'][v], ref), ('jacobian', out['jacobian'][v], Jref),
-                               ('sf', out['sf'][v], B), ('model_jacobian', out['model_jacobian'][v], Jm)):
-            worst[key] = max(worst[key], tol_ratio(got, want, t[key]))
-    print("configs[3], 128 vectors, worst error in propagated tolerance units:", worst)
-    assert max(worst.values()) <= 1.0
-    # ... and three of them against the assembly oracle driven by the TIGHT integrator, section 8(d) propagated
-    po.tight = True
-    for v in (0, 64, 127):
-        ref, sims, B = po.residuals(thetas[v], return_parts=True)
-        Jm = po.model_jacobian(thetas[v])
-        Jref = po.calc_project_jacobian(thetas[v])
-        tau_s, tau_Jm = tight_taus(a, sims, Jm)
-        t = project_tolerances(a, sims, B, tau_s, Jm, tau_Jm)
-        assert tol_ratio(out['residuals'][v], ref, t['residuals']) <= 1.0
-        assert tol_ratio(out['jacobian'][v], Jref, t['jacobian']) <= 1.0
-        assert tol_ratio(out['model_jacobian'][v], Jm, t['model_jacobian']) <= 1.0
+        e, _, _ = errors(v, False)
+        if max(e.values()) > 1.0:
+            over.append(v)
+        for k in keys:
+            worst[k] = max(worst[k], e[k])
+    print("configs[3], 128 vectors, worst error against the LSODA-driven oracle in propagated tolerance units:", worst,
+          "; vectors beyond 1:", over)
+    # Where a vector disagrees with the LSODA-driven oracle the disagreement must be LSODA's (as in the trajectory
+    # sweep above): against the oracle driven by the TIGHT integrator, with section 8(d) propagated, the GPU passes
+    # and the LSODA-driven oracle itself does not do better.  Three more vectors take the tight check regardless.
+    assert len(over) <= 8
+    for v in sorted(set(over) | {0, 64, 127}):
+        e_tight, want_t, tol_t = errors(v, True)
+        assert max(e_tight.values()) <= 1.0, (v, e_tight)
+        if v in over:
+            _, want_l, _ = errors(v, False)
+            lsoda_vs_tight = max(tol_ratio(want_l[k], want_t[k], tol_t[k]) for k in keys)
+            assert lsoda_vs_tight > max(e_tight.values()), (v, lsoda_vs_tight, e_tight)
     del torch
