@@ -43,7 +43,8 @@ def run_configs1(model, gm, dev, reps=3, cpu=True):
     st = torch.empty((V,), dtype=torch.int32, device=dev)
     out = {"workload": "configs[1]: cascade20, 4096 parameter vectors, state only (20 ODEs), 16 output times"}
     for label, o, bytes_note in (
-            ('dopri45', _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12), 'DOPRI45 rtol=1e-9 atol=1e-12'),
+            ('dopri45', _lib.make_opts('dopri45', **{k: model.integrator_options[k] for k in ('rtol', 'atol')}),
+             'DOPRI45 at the default tolerances rtol=%g atol=%g' % (model.integrator_options['rtol'], model.integrator_options['atol'])),
             ('rk4_fixed_4096', _lib.make_opts('rk4', n_steps=4096, t_end=100.0), 'RK4, 4096 fixed steps')):
         ms = _events(torch, dev, lambda: dm.simulate_dev(Pd, tg, None, o, Y, st, ns, None), reps)
         steps = int(ns.sum().item())
@@ -97,7 +98,7 @@ def run_configs3(model, gm, dev, reps=3, cpu=True):
     Yk = torch.empty((V * E, len(tg), 20), dtype=torch.float64, device=dev)
     Sk = torch.empty((V * E, len(tg), 20, 40), dtype=torch.float64, device=dev)
     nk = torch.empty((V * E,), dtype=torch.int32, device=dev)
-    opts = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12)
+    opts = _lib.make_opts('dopri45', **{k: model.integrator_options[k] for k in ('rtol', 'atol')})   # as the pass above
     k_ms = _events(torch, dev, lambda: dm.sens_dev(Pd, tg, None, opts, Yk, Sk, None, nk, None), reps)
     k_steps = int(nk.sum().item())
     out = {"workload": "configs[3]: 8 experiment settings x 1024 vectors (8192 trajectories of 820 ODEs), residuals + "
@@ -354,7 +355,7 @@ def run_dense(model, gm, dev, reps=3, cpu=True):
     """SURVEY.md section 8(d) / BASELINE north_star: "MFMA only if the sensitivity-RHS Jacobian x S product is
     actually dense enough to pay".  The same DOPRI45 driver, the same ensemble shape (4096 vectors, 16 outputs) on
     20-state networks whose df/dy has 40 (the cascade), 60, 120, 220 and 400 (dense) non-zeros: the scalar kernels
-    (AUTO: what the library picks) against SBM_VARIANT_MFMA (v_mfma_f64_16x16x4_f64 tiles, cost independent of the
+    (the row-group kernel, what AUTO picks for sparse Jacobians) against SBM_VARIANT_MFMA (v_mfma_f64_16x16x4_f64 tiles, cost independent of the
     sparsity).  No CPU leg: same workload family as the headline."""
     import torch
     from sysbio_modeling_amd import _lib, models_zoo
@@ -379,7 +380,7 @@ def run_dense(model, gm, dev, reps=3, cpu=True):
         models.append((spec.name, mm))
     for name, mm in models:
         row = {"nnz_jy": int(mm.generated.hip_source.split('NNZ_JY = ')[1].split(';')[0])}
-        for label, variant in (('valu', 'auto'), ('mfma', 'mfma')):
+        for label, variant in (('valu', 'row_group'), ('mfma', 'mfma')):
             o = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant=variant)
             ms = _events(torch, dev, lambda: mm.device_model.sens_dev(Pd, tg, None, o, Y, S, st, ns, None), reps)
             steps = int(ns.sum().item())

@@ -53,16 +53,16 @@ enum {
    * with step_mult = m every substep is cut into m parts, so that the grids of runs with
    * different step_mult are nested (what the h^2 expansion needs).                           */
   SBM_IMPLICIT_MIDPOINT_GRADED = 3,
-  /* Stiff systems in ONE call: implicit midpoint with error control inside the kernel.  A coarse solution (steps H)
-   * and a fine one (steps H/2, nested grid) are carried side by side and never mixed; what is written at an output
-   * time is their passive extrapolation (4 fine - coarse)/3 (the symmetric rule's error expands in H^2: fourth
-   * order), and (fine - coarse)/3 there is the error estimate: too large at any output time and the trajectory
-   * starts over with more steps per unit time (at most 12 passes; one restart is the rule).  rtol / atol as for
-   * DOPRI45 (state AND sensitivities, column by column); h0 = coarse step of the first pass (<= 0: span / 256).
-   * The first step is graded as in SBM_IMPLICIT_MIDPOINT_GRADED.  What method='auto' of the Python classes
-   * switches to for vectors DOPRI45 gives up on -- the role of LSODA's own switch to BDF
-   * (model/ode_model.py:122-123).  n_steps counts the coarse steps of the accepted pass (each goes with two fine
-   * steps: three midpoint solves), n_reject those of the abandoned passes. */
+  /* Stiff systems in ONE call: implicit midpoint with error control inside the kernel.  Three solutions (steps H,
+   * H/2, H/4 on nested grids) are carried side by side and never mixed; the symmetric rule's error expands in H^2,
+   * so T22 = (4 y_{H/2} - y_H)/3 and T32 = (4 y_{H/4} - y_{H/2})/3 are fourth-order results at every output time:
+   * T32 is written, |T32 - T22|/3 is the error estimate -- too large at any output time and the trajectory starts
+   * over with more steps per unit time (at most 12 passes; one restart is the rule).  rtol / atol as for DOPRI45
+   * (state AND sensitivities, column by column); h0 = coarse step of the first pass (<= 0: span / 64).  The first
+   * step is graded as in SBM_IMPLICIT_MIDPOINT_GRADED.  What method='auto' of the Python classes switches to for
+   * vectors DOPRI45 gives up on -- the role of LSODA's own switch to BDF (model/ode_model.py:122-123).  n_steps
+   * counts the coarse steps of the accepted pass (each goes with 2 + 4 finer steps: seven midpoint solves),
+   * n_reject those of the abandoned passes. */
   SBM_IMPLICIT_ADAPTIVE = 4
 };
 

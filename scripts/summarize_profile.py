@@ -11,7 +11,7 @@ usage: python scripts/summarize_profile.py gpurun_out/<tag> profiles/<round>
         valu_insts_per_step    SQ_INSTS_VALU / accepted steps
         cycles_per_valu_inst   4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU   (the counter ticks in quad-cycles)
         valu_busy_fraction     SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES * resident waves per SIMD  (= share of the SIMD's
-                               issue slots; waves per SIMD from the launch's register allocation)
+                               issue slots; waves per SIMD from the launch's register and LDS allocation)
         lds_conflict_share     SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
 import collections
@@ -36,12 +36,17 @@ KEYS = {
 }
 
 
-def waves_per_simd(vgpr, agpr):
+def waves_per_simd(vgpr, agpr, lds):
+    """Resident waves per SIMD of a 64-thread workgroup kernel.  rocprofv3's VGPR_Count on gfx950 is in units of two
+    registers (the row-group kernel's 256 VGPRs read "128"); LDS: 160 KiB per CU, four SIMDs."""
     try:
-        alloc = -(-(int(vgpr) + int(agpr or 0)) // 8) * 8
+        regs = 2 * (int(vgpr) + int(agpr or 0))
+        alloc = -(-regs // 8) * 8
+        by_regs = max(1, min(8, 512 // max(alloc, 1)))
+        by_lds = 8 if not int(lds or 0) else max(1, (160 * 1024 // int(lds)) // 4)
     except (TypeError, ValueError):
         return None
-    return max(1, min(8, 512 // max(alloc, 1)))
+    return min(by_regs, by_lds)
 
 
 def read_pmc(src):
@@ -92,10 +97,18 @@ def main(src, dst):
         except (OSError, ValueError, IndexError):
             pass
         summary = read_pmc(wdir)
-        if not summary:
-            continue
-        with open(os.path.join(dst, '%s_pmc_summary.json' % w), 'w') as fh:
-            json.dump(summary, fh, indent=1)
+        if summary:
+            with open(os.path.join(dst, '%s_pmc_summary.json' % w), 'w') as fh:
+                json.dump(summary, fh, indent=1)
+        else:      # the raw counter files are gone (they stay on the GPU box): work from the kept summary
+            try:
+                with open(os.path.join(dst, '%s_pmc_summary.json' % w)) as fh:
+                    summary = json.load(fh, object_pairs_hook=collections.OrderedDict)
+                if plain is None:
+                    with open(os.path.join(dst, '%s_plain.json' % w)) as fh:
+                        plain = json.load(fh)
+            except (OSError, ValueError):
+                continue
         for key, (kw, rx, steps_path, per_pass) in KEYS.items():
             if kw != w:
                 continue
@@ -133,9 +146,9 @@ def main(src, dst):
                 if av:
                     out['cycles_per_valu_inst'] = 4.0 * av['total'] / iv['total']
                     wc = e.get('SQ_WAVE_CYCLES')
-                    wps = waves_per_simd(e['launch']['vgpr'], e['launch']['agpr'])
+                    wps = waves_per_simd(e['launch']['vgpr'], e['launch']['agpr'], e['launch']['lds'])
                     if wc and wps:
-                        out['waves_per_simd_by_registers'] = wps
+                        out['waves_per_simd'] = wps
                         out['valu_active_share_of_wave_lifetime'] = av['total'] / wc['total']
                         out['valu_busy_fraction'] = min(1.0, av['total'] / wc['total'] * wps)
             if 'SQ_LDS_BANK_CONFLICT' in e and e.get('SQ_LDS_IDX_ACTIVE', {}).get('total'):

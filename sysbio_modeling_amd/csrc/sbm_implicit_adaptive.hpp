@@ -5,47 +5,47 @@
 // (sbm_imid_kernel) needed a host loop around it for that (whole-ensemble runs with n, 2n, 4n, ... steps combined in a
 // Romberg table: _control.py -- seconds per ensemble).  Here the control sits inside the kernel, one launch:
 //
-//   Two solutions are carried side by side and NEVER mixed: a coarse one (steps of size H) and a fine one (steps
-//   of size H/2 on the nested grid).  The implicit midpoint rule is symmetric, so both have global errors that expand
-//   in H^2, and what is written at an output time is the PASSIVE extrapolation (4 fine - coarse) / 3 (fourth order);
-//   (fine - coarse) / 3 at the output times estimates the global error of the fine solution.  Too large at any output
-//   time: the trajectory starts over with more steps per unit time (the estimate falls as n^-2: n <- n sqrt(est)
-//   with a margin, so one restart is the rule, and a pass that is clearly failing is abandoned at its first bad
-//   output).  Every pass uses ONE step size per output interval -- see below why.
+//   THREE solutions are carried side by side and never mixed: steps of size H, H/2 and H/4 on nested grids.  The
+//   implicit midpoint rule is symmetric, so all three have global errors that expand in H^2; at an output time
+//       T22 = (4 y_{H/2} - y_H) / 3   and   T32 = (4 y_{H/4} - y_{H/2}) / 3
+//   are two fourth-order results (passive extrapolation), T32 is written out and |T32 - T22| / 3 bounds its error as
+//   long as the error falls by at least 4 per halving -- the acceptance rule of the round-1 host loop (_control.py:
+//   it held on stiff50 where order reduction leaves second order, and in the asymptotic regime where the ratio is
+//   16), now per trajectory inside the kernel.  Too large at any output time: the trajectory starts over with more
+//   steps per unit time (the estimate falls as n^-4 at best: n <- n (est / 0.5)^(1/4) with a margin; a pass that is
+//   clearly failing is abandoned at its first bad output).  Every pass uses ONE step size per output interval -- see
+//   below why.  rtol / atol mean what they mean for DOPRI45: no calibration constant.
 //
-// Two designs that were built first and measured, and why they are not here:
+// Three designs that were built first and measured, and why they are not here:
 //  * Step doubling with local extrapolation (advance with (4 fine - coarse) / 3 after every macro step) is UNSTABLE
 //    on stiff systems: the midpoint rule's amplification factor tends to -1 for h lambda -> -infinity (A- but not
 //    L-stable), two half steps give +1, so the locally extrapolated step multiplies a stiff deviation by
 //    (4 - (-1)) / 3 = 5/3.  Its controller saved the run by keeping h |lambda| = O(1): 275 000 steps per vector on
 //    stiff50 where 4096 suffice.
-//  * Keeping the two solutions apart but choosing the step count per OUTPUT INTERVAL (retry an interval from its
-//    start) works for the state and fails for the sensitivities: every change of the step size leaves a deviation of
-//    the stiff components from the numerical slow manifold, the rule damps it by only 1 - O(1/(h lambda)) per step,
-//    and the estimator then sees an oscillation of fixed size that no refinement of the interval removes (a third of
-//    the stiff50 vectors stalled around the fifth interval).  A uniform grid from t0 excites nothing.
+//  * Keeping the solutions apart but choosing the step count per OUTPUT INTERVAL (retry an interval from its start)
+//    works for the state and fails for the sensitivities: every change of the step size leaves a deviation of the
+//    stiff components from the numerical slow manifold, the rule damps it by only 1 - O(1/(h lambda)) per step, and
+//    the estimator then sees an oscillation of fixed size that no refinement of the interval removes (a third of the
+//    stiff50 vectors stalled around the fifth interval).  A uniform grid from t0 excites nothing.
+//  * TWO solutions (H, H/2) with (fine - coarse) / 3 as the estimate: that is the error of the SECOND-order fine
+//    solution, while the fourth-order combination is what is returned -- e4 = (C4 / C2^2) e2^2 with a problem-dependent
+//    constant.  Calibrated on stiff50 (estimate held at sqrt(tol)) it took 0.95 s per 4096 vectors, 7000 coarse steps
+//    on average where 2048 + 4096 + 8192 fixed steps give the same accuracy, and was 4 tolerance units off on a
+//    binding motif with an initial layer.  The third solution costs 7 midpoint solves per coarse step instead of 3
+//    and buys an estimate of the error that is actually returned.
 //
-// The estimate belongs to the SECOND-order fine solution while the FOURTH-order combination is what is returned:
-// global errors e2 = C2 H^2 and e4 = C4 H^4 = (C4 / C2^2) e2^2, so a tolerance tol on the returned values is met with
-// the estimate held at SBM_IMAD_KAPPA sqrt(tol); the constant (it stands for sqrt(C2^2 / C4); 1.0) is calibrated on
-// stiff50 against a tight LSODA solution (tests/golden/stiff50_tight.npz) and checked on the other models of
-// tests/test_gpu_implicit.py.  Error norm as in the explicit kernels:
-// max(RMS over the state, max over the sensitivity columns of the column RMS), every element against
-// atol + rtol |value|.  The first step of a trajectory is graded (13 geometric substeps, as
-// SBM_IMPLICIT_MIDPOINT_GRADED; cut once more in the fine solution): the reference always starts from y = 0, possibly
-// off a fast manifold.
+// Error norm as in the explicit kernels: max(RMS over the state, max over the sensitivity columns of the column RMS),
+// every element against atol + rtol max(|value|, 1e-6 x the largest entry of its column so far).  The first step of a
+// trajectory is graded (13 geometric substeps, as SBM_IMPLICIT_MIDPOINT_GRADED; cut again in the finer solutions): the
+// reference always starts from y = 0, possibly off a fast manifold.
 //
 // Mapping: that of sbm_imid_kernel (lane j = column j of S with all NV rows in registers, lane i = state component i,
 // row lanes evaluate f_i / J_y / J_p by class; sparse LU from emit_implicit.py, distributed for triangular patterns).
 // Registers: the S columns of the solution being advanced and the solver's work vector b, as in the fixed-step
-// kernel; the other solution's columns wait in LDS ([row][lane], 8 NV 64 bytes).  J_p reaches the columns through a compact table
+// kernel; the other two solutions' columns wait in LDS ([row][column], 2 x 8 NV NKc bytes).  J_p reaches the columns through a compact table
 // (RL_MAXJP values per row, picked by column index) when rows have few parameter entries, through the dense
 // [row][64] table otherwise.
 #pragma once
-
-#ifndef SBM_IMAD_KAPPA
-#define SBM_IMAD_KAPPA 1.0
-#endif
 
 template <class M>
 struct SbmImadShared {
@@ -55,7 +55,9 @@ struct SbmImadShared {
   double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
   double MF[M::IM_NM + 2];      // IM_TRI: reciprocal pivots and scaled entries, written row by row lane
   double A[A_SPARSE ? (M::NV * M::RL_MAXJP + 2) : (M::NV * 64 + 2)];   // J_p: [row][slot] or [row][column]
-  double ZO[M::NV * 64];        // S of the solution that is NOT being advanced at the moment, [row][lane]
+  static constexpr int ZC = M::NK < 64 ? M::NK : 64;     // columns of a chunk that exist
+  static constexpr int ZS = ZC < 64 ? ZC + 1 : 64;       // + one spare column that the idle lanes share (all zeros)
+  double ZO[2][M::NV * ZS];     // S of the two solutions that are NOT being advanced at the moment, [row][column]
 };
 
 template <class M>
@@ -215,13 +217,15 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
   const double* tg = a.t_out + goff;
   const bool with_sens = a.S != nullptr;   // wave-uniform
 
-  double zc[NV];                   // S of the solution being advanced (the other one waits in sh.ZO)
-  double yc = 0.0, yf = 0.0;
+  // the three solutions: index 0 = steps H, 1 = H/2, 2 = H/4.  One of them is "active" (state component in ya, S
+  // columns in za), the other two wait in sh.ZO / yw.
+  double za[NV];
+  double yw[3] = {0.0, 0.0, 0.0};
+  constexpr int ZS = Sh::ZS;
+  const int zl = lane < Sh::ZC ? lane : ZS - 1; // idle lanes (beyond the chunk's columns) share the spare column: all zeros
   double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
   double* St = a.S ? a.S + (size_t)traj * a.n_t * NV * NK : nullptr;
   const double rtol = a.opts.rtol > 0.0 ? a.opts.rtol : 1e-9, atol = a.opts.atol > 0.0 ? a.opts.atol : 1e-12;
-  const double tau = SBM_IMAD_KAPPA * sqrt(rtol);            // see the header
-  const double tau_abs = tau * (atol / rtol);
   const double nrtol = 0.03 * rtol;
   const long long max_steps = a.opts.max_steps > 0 ? a.opts.max_steps : (a.opts.max_steps < 0 ? -(long long)a.opts.max_steps : 4000000LL);
   constexpr int GRADE = 12;
@@ -230,21 +234,29 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
   long long n_acc = 0, n_rej = 0;
   const double t_span = glen > 0 ? tg[glen - 1] - a.opts.t0 : 0.0;
   // coarse steps per unit time of the first pass
-  double density = a.opts.h0 > 0.0 ? 1.0 / a.opts.h0 : 256.0 / (t_span > 0.0 ? t_span : 1.0);
+  double density = a.opts.h0 > 0.0 ? 1.0 / a.opts.h0 : 64.0 / (t_span > 0.0 ? t_span : 1.0);
 
   bool done = false, complete = false;
   for (int pass = 0; pass < MAXPASS && !done; ++pass) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { zc[i] = (a.s0 && has_col) ? a.s0[i * NK + col] : 0.0; sh.ZO[i * 64 + lane] = zc[i]; }
-    yc = (a.y0 && has_row) ? a.y0[lane] : 0.0;
-    yf = yc;
+    for (int i = 0; i < NV; ++i) {
+      za[i] = (a.s0 && has_col) ? a.s0[i * NK + col] : 0.0;
+      sh.ZO[0][i * ZS + zl] = za[i];
+      sh.ZO[1][i * ZS + zl] = za[i];
+    }
+    const double y_init = (a.y0 && has_row) ? a.y0[lane] : 0.0;
+    yw[0] = yw[1] = yw[2] = y_init;
+    // who is where: active solution, and which solution each LDS slot holds.  The steps run 0, 1, 2 then 2, 1, 0
+    // then 0, 1, 2 ...: two exchanges with LDS per coarse step instead of three.
+    int active = 0, slot0 = 1, slot1 = 2;
     double t = a.opts.t0;
-    double colmax = 0.0;          // largest |S| entry of this lane's column so far (both solutions agree on its size)
+    double colmax = 0.0;          // largest |S| entry of this lane's column so far
     float err_max = 0.f;
     int rc = SBM_OK;
     long long n_pass = 0;
-    bool first_step = true, abandoned = false;
-    double dyc = 0.0, dyf = 0.0, H_prev = 0.0;    // previous increments: Newton predictors
+    bool first_step = true, abandoned = false, forward = true;
+    double dyp[3] = {0.0, 0.0, 0.0};   // previous increment of each solution over a coarse step: Newton predictors
+    double H_prev = 0.0;
     int io = 0;
     for (; io < glen && rc == SBM_OK && !abandoned; ++io) {
       const double target = tg[io];
@@ -254,28 +266,35 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
         const int n = nd < 1.0 ? 1 : (nd > 2.0e9 ? 2000000000 : (int)nd);
         if (n_acc + n_rej + n_pass + n > max_steps) { rc = SBM_MAX_STEPS; break; }
         const double H = dt / n;
-        const float ymax = sbm_wave_max(has_row ? (float)fabs(yf) : 0.f);
+        const float ymax = sbm_wave_max(has_row ? (float)fabs(yw[2]) : 0.f);
         const double natol = fmax(0.03 * atol, 4.0e-16 * (double)ymax);
         const double sc_h = H_prev > 0.0 ? H / H_prev : 0.0;
-        dyc *= sc_h;
-        dyf *= sc_h;
+        dyp[0] *= sc_h; dyp[1] *= sc_h; dyp[2] *= sc_h;
         H_prev = H;
         for (int s = 0; s < n && rc == SBM_OK; ++s) {
           const double ts = fma((double)s, H, t);
-          // The coarse solution takes this step in one piece, the fine one in two; the very first step of the
-          // trajectory is graded (pieces H 2^-GRADE, 2^-GRADE, 2^-(GRADE-1), ..., 1/2, each cut once more in the fine
-          // solution: nested grids).  ONE copy of the step code serves all of it, working on (yc, zc): the two
-          // solutions trade places after each phase (a register swap, ~6 NV moves per step against ~20 NV of solver
-          // arithmetic), the waiting one parked in LDS.  Two inlined copies of Newton + solve, a third NV-row
-          // array to work in, or both solutions in registers overflow the register file (measured: 999, 380 and 262
-          // scratch instructions).
+          // ONE copy of the step code (Newton + column solve) serves the three solutions and the graded first step:
+          // two inlined copies, a third NV-row array to work in, or two solutions in registers overflow the register
+          // file (measured: 999, 380 and 262 scratch instructions).
 #pragma unroll 1
-          for (int phase = 0; phase < 2; ++phase) {
-            const bool fine = phase == 1;
+          for (int ph = 0; ph < 3; ++ph) {
+            const int want = forward ? ph : 2 - ph;
+            if (want != active) {
+              // bring solution `want` in, park the active one in its slot
+              const int sl = slot0 == want ? 0 : 1;     // (an LDS offset: no register array is indexed by it)
+              if (with_sens) {
+                double* zo = sh.ZO[sl];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) { const double tmp = zo[i * ZS + zl]; zo[i * ZS + zl] = za[i]; za[i] = tmp; }
+              }
+              if (sl == 0) slot0 = active; else slot1 = active;
+              active = want;
+            }
             if (rc == SBM_OK) {
-              const double ystart = yc;
-              double dy_pred = fine ? 0.5 * dyf : dyc;
-              const int parts = fine ? 2 : 1;
+              double ya = want == 0 ? yw[0] : (want == 1 ? yw[1] : yw[2]);
+              const double ystart = ya;
+              const int parts = 1 << want;
+              double dy_pred = (want == 0 ? dyp[0] : (want == 1 ? dyp[1] : dyp[2])) / parts;
               const int nops = first_step ? (GRADE + 1) * parts : parts;
               double tt = ts;
 #pragma unroll 1
@@ -286,63 +305,56 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
                   h = ldexp(H, -(gj == 0 ? GRADE : GRADE - gj + 1)) / parts;
                   dy_pred = 0.0;
                 }
-                const double y_before = yc;
-                double yb = fma(0.5, dy_pred, yc);
-                rc = st.newton(tt + 0.5 * h, 0.5 * h, yc, yb, nrtol, natol, n_newton);
+                const double y_before = ya;
+                double yb = fma(0.5, dy_pred, ya);
+                rc = st.newton(tt + 0.5 * h, 0.5 * h, ya, yb, nrtol, natol, n_newton);
                 if (rc == SBM_OK) {
-                  yc = fma(2.0, yb, -yc);
-                  if (with_sens) st.sens(0.5 * h, zc);
+                  ya = fma(2.0, yb, -ya);
+                  if (with_sens) st.sens(0.5 * h, za);
                 }
-                dy_pred = yc - y_before;      // the second half of a fine step starts from the first half's increment
+                dy_pred = ya - y_before;      // the next piece starts from this piece's increment
                 tt += h;
               }
-              if (fine) dyf = yc - ystart; else dyc = yc - ystart;
+              const double inc = ya - ystart;
+              if (want == 0) { yw[0] = ya; dyp[0] = inc; } else if (want == 1) { yw[1] = ya; dyp[1] = inc; } else { yw[2] = ya; dyp[2] = inc; }
             }
-            // trade places: (yc, zc) <-> (yf, sh.ZO); after the second phase everything is back under its own name
-            if (with_sens) {
-#pragma unroll
-              for (int i = 0; i < NV; ++i) { const double tmp = sh.ZO[i * 64 + lane]; sh.ZO[i * 64 + lane] = zc[i]; zc[i] = tmp; }
-            }
-            { const double tmp = yc; yc = yf; yf = tmp; }
           }
+          forward = !forward;
           first_step = false;
         }
         n_pass += n;
         t = target;
       }
       if (rc != SBM_OK) break;
-      // (fine - coarse) / 3: the global error of the fine solution at this output time
+      // ---- output time: T22 = (4 y1 - y0) / 3, T32 = (4 y2 - y1) / 3; write T32, |T32 - T22| / 3 bounds its error ----
+      // (the active solution is 0 or 2 here; fetch the other two from their slots)
       float cs = 0.f;
       if (with_sens) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) colmax = fmax(colmax, fabs(zc[i]));
+        const int s1 = slot0 == 1 ? 0 : 1;                 // slot of solution 1 (never active at an output time)
+        const int so = 1 - s1;                              // slot of the other waiting solution
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          const double zfi = sh.ZO[i * 64 + lane];
-          const double e = (zfi - zc[i]) * (1.0 / 3.0);
-          // entries below 1e-6 of their column's largest are judged against that (SURVEY.md section 8(d)'s floor)
-          const float r = (float)e * __builtin_amdgcn_rcpf((float)fma(tau, fmax(fabs(zfi), 1e-6 * colmax), tau_abs));
+          const double z1 = sh.ZO[s1][i * ZS + zl], zo = sh.ZO[so][i * ZS + zl];
+          const double z0 = active == 0 ? za[i] : zo, z2 = active == 0 ? zo : za[i];
+          const double t32 = fma(z2 - z1, 1.0 / 3.0, z2), t22 = fma(z1 - z0, 1.0 / 3.0, z1);
+          colmax = fmax(colmax, fabs(t32));
+          const float r = (float)((t32 - t22) * (1.0 / 3.0)) *
+                          __builtin_amdgcn_rcpf((float)fma(rtol, fmax(fabs(t32), 1e-6 * colmax), atol));
           cs = fmaf(r, r, cs);
+          if (St && has_col) St[((size_t)io * NV + i) * NK + col] = t32;
         }
       }
-      const double ey = (yf - yc) * (1.0 / 3.0);
-      const float ymax_now = sbm_wave_max(has_row ? (float)fabs(yf) : 0.f);
-      const float ry = has_row ? (float)ey * __builtin_amdgcn_rcpf((float)fma(tau, fmax(fabs(yf), 1e-6 * (double)ymax_now), tau_abs)) : 0.f;
+      const double y32 = fma(yw[2] - yw[1], 1.0 / 3.0, yw[2]), y22 = fma(yw[1] - yw[0], 1.0 / 3.0, yw[1]);
+      const float ymax_now = sbm_wave_max(has_row ? (float)fabs(y32) : 0.f);
+      const float ry = has_row ? (float)((y32 - y22) * (1.0 / 3.0)) *
+                                     __builtin_amdgcn_rcpf((float)fma(rtol, fmax(fabs(y32), 1e-6 * (double)ymax_now), atol)) : 0.f;
       const float xs = sbm_wave_sumf(sbm_nan_to_inf(ry * ry));
       const float mx = sbm_wave_max(has_col ? sbm_nan_to_inf(cs) : 0.f);
       const float err = sqrtf(fmaxf(mx, xs) * (1.0f / NV));
       if (!(err < 3.0e38f)) { rc = SBM_NON_FINITE; break; }
       err_max = fmaxf(err_max, err);
-      // passive extrapolation, for the output only
-      if (Yt && has_row && chunk == 0) Yt[(size_t)io * NV + lane] = fma(yf - yc, 1.0 / 3.0, yf);
-      if (St && has_col) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const double zfi = sh.ZO[i * 64 + lane];
-          St[((size_t)io * NV + i) * NK + col] = fma(zfi - zc[i], 1.0 / 3.0, zfi);
-        }
-      }
-      if (err_max > 4.0f && pass + 1 < MAXPASS) abandoned = true;    // clearly not good enough: do not finish the pass
+      if (Yt && has_row && chunk == 0) Yt[(size_t)io * NV + lane] = y32;
+      if (err_max > 16.0f && pass + 1 < MAXPASS) abandoned = true;    // clearly not good enough: do not finish the pass
     }
     complete = rc == SBM_OK && !abandoned;
     if (complete && err_max <= 1.0f) {
@@ -355,7 +367,8 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
     } else {
       n_rej += n_pass;
       double grow = 4.0;                                     // Newton failure / non-finite values: a much finer grid
-      if (rc == SBM_OK) grow = fmin(16.0, fmax(1.5, 1.25 * sqrt((double)err_max / 0.5)));
+      // the estimate falls by 16 per halving in the asymptotic regime, by 4 under order reduction: between the two
+      if (rc == SBM_OK) grow = fmin(8.0, fmax(1.3, 1.15 * pow((double)err_max / 0.5, 0.3)));
       density *= grow;
       if (pass + 1 == MAXPASS) status = rc != SBM_OK ? rc : SBM_TOL_NOT_REACHED;
     }

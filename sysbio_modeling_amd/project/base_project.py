@@ -570,6 +570,7 @@ class Project(object):
     def _opts(self, **overrides):
         o = self._options(**overrides)
         levels = int(o.pop('extrapolate', 0) or 0)
+        _lib.implicit_adaptive_defaults(o, set(overrides) | set(self.integrator_options))
         fixed = ('rk4', 'rk4_fixed') + _lib.FIXED_STEP_IMPLICIT
         if str(o.get('method', 'dopri45')).lower() in fixed and not o.get('h0', 0) > 0:
             o['t_end'] = max(g[-1] for g in self._rows['grids'])
@@ -649,9 +650,9 @@ class Project(object):
             def implicit(idx):
                 # one device call: the implicit integrator with in-kernel error control (SBM_IMPLICIT_ADAPTIVE)
                 t = th[torch.as_tensor(idx, device=th.device, dtype=torch.long)]
-                return split(self._evaluate_once(t, jacobian, want, method='implicit_adaptive', rtol=rtol,
-                                                 atol=max(atol, 1e-3 * rtol),     # (see OdeModel._run_auto)
-                                                 extrapolate=0, max_steps=0, **keep)) + (None,)
+                oi = _lib.implicit_adaptive_defaults(dict(method='implicit_adaptive', rtol=rtol, atol=atol),
+                                                     set(integrator_overrides) | set(self.integrator_options))
+                return split(self._evaluate_once(t, jacobian, want, extrapolate=0, max_steps=0, **oi, **keep)) + (None,)
             out, st, steps, stiff = _control.with_stiff_fallback(
                 lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=-budget,
                                                   rtol=rtol, atol=atol, extrapolate=0, **keep)),

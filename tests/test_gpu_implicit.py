@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from tests import reference_cases as rc
-from tests.conftest import parity_err, check_parity
+from tests.conftest import parity_err, check_parity, tol_ratio, lsoda_taus, project_tolerances
 
 pytestmark = pytest.mark.gpu
 
@@ -174,7 +174,7 @@ def test_in_kernel_controlled_implicit_integrator(gpu_models, golden):
     t_out = _from_zero(g['t'][g['idx']])
     S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled')
     info = m.last_info
-    assert info['status'].tolist() == [0, 0, 0] and np.all(info['n_steps'] >= 256)
+    assert info['status'].tolist() == [0, 0, 0] and np.all(info['n_steps'] >= 64)
     ey = check_parity(Y[:, 1:], g['Y'], gt['Y'], what='stiff50 states', criterion='parity')
     es = check_parity(S[:, 1:], g['S'], gt['S'], what='stiff50 sensitivities', criterion='parity')
     print("implicit_controlled on stiff50: %s coarse steps (+%s in abandoned passes); error vs LSODA golden y %.2f S %.2f"
@@ -191,7 +191,7 @@ def test_in_kernel_controlled_implicit_integrator(gpu_models, golden):
     # a step budget too small for the tolerance is reported, rows NaN
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        Y3 = m.simulate_batch(P[:1], t_out, method='implicit_controlled', max_steps=300)
+        Y3 = m.simulate_batch(P[:1], t_out, method='implicit_controlled', max_steps=100)
     assert m.last_info['status'].tolist() == [1] and np.all(np.isnan(Y3[0, -1]))
 
 
@@ -307,7 +307,12 @@ def test_project_auto_method_on_the_stiff_model(gpu_models, golden):
     # the single-vector API of the reference takes the method from the project's options
     proj.integrator_options.update(method='auto', max_steps=20000)
     r = proj.residuals(theta[0])
-    assert np.allclose(r, out['residuals'][0], rtol=1e-9, atol=1e-11)
+    # (a state-only run of the controlled implicit integrator: its own step count, the same solution to the parity
+    # tolerance, propagated to the residual rows)
+    a = proj.descriptor_arrays()
+    tau_s, _ = lsoda_taus(a, theta[0], out['sims'][0])
+    tol = project_tolerances(a, out['sims'][0], np.zeros(0), tau_s)
+    assert tol_ratio(r, out['residuals'][0], tol['residuals']) <= 1.0
 
 
 STIFF_MOTIF = """
@@ -370,4 +375,8 @@ def test_graded_first_step_for_inconsistent_initial_conditions():
     assert e_p > 50.0 * e_g, (e_p, e_g)
     S_c, Y_c = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled')
     assert m.last_info['status'].tolist() == [0, 0]
-    assert parity_err(Y_c[:, 1:], Yr) <= 1.0 and parity_err(S_c[:, 1:], Sr) <= 1.0
+    gm.c_library()
+    for v in range(2):
+        tight = lambda v=v: oo.tight_solution(gm, P[v], t_out, use_c=True)[1:]
+        check_parity(np.concatenate([Y_c[v, 1:], S_c[v, 1:]], axis=1), np.concatenate([Yr[v], Sr[v]], axis=1), tight,
+                     what='binding motif, vector %d' % v, criterion='parity')

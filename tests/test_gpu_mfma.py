@@ -52,7 +52,7 @@ def test_mfma_variant_on_a_densely_coupled_network(zoo):
         grid = np.linspace(0, 30.0, 1000)
         idx = np.array([50, 200, 500, 999])
         t_out = _from_zero(grid[idx])
-        Sa, Ya = m.calc_jacobian_batch(P, t_out, return_states=True)
+        Sa, Ya = m.calc_jacobian_batch(P, t_out, return_states=True, variant='row_group')
         Sb, Yb = m.calc_jacobian_batch(P, t_out, return_states=True, variant='mfma')
         assert m.last_info['status'].tolist() == [0] * 5
         assert np.allclose(Ya, Yb, rtol=1e-9, atol=1e-12) and np.allclose(Sa, Sb, rtol=1e-8, atol=1e-11)
