@@ -321,6 +321,27 @@ def variant_extras(model, dev, theta_p, tg, rk4_steps):
         ex["sens_dopri45_%s" % variant] = t(_lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant=variant))
         ex["sens_rk4_fixed_%d_%s" % (rk4_steps, variant)] = t(_lib.make_opts('rk4', n_steps=rk4_steps, t_end=100.0,
                                                                              variant=variant))
+    # the reference's own fixture size: Michaelis-Menten (2 states, 5 parameters: 12 coupled ODEs), 4096 vectors with
+    # sensitivities -- one trajectory per wavefront (row-group / row-lane) against eight per wavefront (packed)
+    try:
+        from sysbio_modeling_amd.symbolic import zoo_model
+        from sysbio_modeling_amd.model import OdeModel
+        gmm = zoo_model('michaelis_menten')
+        mm = OdeModel(gmm.model, gmm.sens_model, gmm.n_vars, gmm.param_order, use_jit=False)
+        mm.enable_jit(dm.ctx)
+        rng = np.random.default_rng(1)
+        Pm = torch.from_numpy(np.array([1e-3, 1e-3, 0.01, 0.01, 1e-3])[None, :] * np.exp(0.3 * rng.standard_normal((4096, 5)))).to(dev)
+        tm = torch.linspace(0.0, 100.0, 17, dtype=torch.float64, device=dev)
+        Ym = torch.empty((4096, 17, 2), dtype=torch.float64, device=dev)
+        Sm = torch.empty((4096, 17, 2, 5), dtype=torch.float64, device=dev)
+        nsm = torch.empty((4096,), dtype=torch.int32, device=dev)
+        for variant in ('row_group', 'row_lane', 'packed'):
+            o = _lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant=variant)
+            ms = _events(torch, dev, lambda: mm.device_model.sens_dev(Pm, tm, None, o, Ym, Sm, None, nsm, None), 5)
+            stp = int(nsm.sum().item())
+            ex["small_model_michaelis_menten_sens_%s" % variant] = {"ms": ms, "steps": stp, "steps_per_s": stp / (ms * 1e-3)}
+    except Exception as e:   # noqa: BLE001
+        ex["small_model_michaelis_menten_sens"] = {"error": repr(e)[:200]}
     # a model beyond one row / one column per lane: 70 states, 140 parameters, 9870 coupled ODEs per trajectory
     try:
         from sysbio_modeling_amd import models_zoo

@@ -78,7 +78,7 @@ typedef struct sbm_integrator_opts {
   double t0;         /* time of the initial condition; output times must be >= t0.
                       * odeint takes t_sim[0] for it (model/ode_model.py:122,167);
                       * Project always integrates from 0 (base_project.py:419)     */
-  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE | _ROW_GROUP | _SMALL_BATCH | _MFMA */
+  int32_t variant;   /* sensitivity kernel: SBM_VARIANT_AUTO | _PER_WAVE | _ROW_LANE | _ROW_GROUP | _SMALL_BATCH | _MFMA | _PACKED */
   int32_t step_mult; /* fixed-step methods: every output interval is cut into
                       * step_mult * ceil(dt / h0) equal steps (0 = 1).  Doubling it halves every
                       * step exactly, which is what Richardson extrapolation needs.          */
@@ -116,7 +116,12 @@ enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2,
         * Opt-in: on MI355X the f64 matrix rate equals the f64 vector rate, so it pays only for dense Jacobians
         * (DESIGN.md records the measured crossover).  n_vars <= 64, sensitivity entry points, DOPRI45 / RK4; falls
         * back to AUTO otherwise. */
-       SBM_VARIANT_MFMA = 5 };
+       SBM_VARIANT_MFMA = 5,
+       /* Small models (n_vars, n_sens <= 32 and at most 256 sensitivity entries): several trajectories per wavefront, each
+        * in a segment of 4 / 8 / 16 / 32 lanes with its own step-size control.  AUTO takes it from 2048 trajectories on
+        * (a trajectory's numbers do not depend on its wavefront mates, but the step sequence differs in rounding from
+        * the one-trajectory-per-wavefront kernels'); this value forces it for any batch.  Other models: as AUTO. */
+       SBM_VARIANT_PACKED = 6 };
 
 /* per-trajectory status written next to the results (the reference does not
  * check LSODA failures, model/ode_model.py:122,167; non-zero statuses are what

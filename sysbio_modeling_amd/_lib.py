@@ -140,7 +140,7 @@ def dev_ptr(t):
 IMPLICIT_ADAPTIVE = ('implicit_adaptive', 'implicit', 'imid_adaptive', 'implicit_controlled', 'implicit_auto', 'stiff')
 IMPLICIT_GRADED = ('implicit_midpoint_graded', 'imid_graded')
 FIXED_STEP_IMPLICIT = ('implicit_midpoint', 'imid', 'midpoint') + IMPLICIT_GRADED
-VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3, 'small_batch': 4, 'mfma': 5}
+VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3, 'small_batch': 4, 'mfma': 5, 'packed': 6}
 
 
 def implicit_adaptive_defaults(o, explicit):

@@ -211,7 +211,7 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
     return sbm_fail(SBM_E_ARG, "%s: unknown method %d", who, o->method);
   }
   if (o->step_mult < 0 || o->step_mult > 65536) return sbm_fail(SBM_E_ARG, "%s: step_mult %d", who, o->step_mult);
-  if (o->variant < SBM_VARIANT_AUTO || o->variant > SBM_VARIANT_MFMA)
+  if (o->variant < SBM_VARIANT_AUTO || o->variant > SBM_VARIANT_PACKED)
     return sbm_fail(SBM_E_ARG, "%s: unknown kernel variant %d", who, o->variant);
   return 0;
 }

@@ -1342,6 +1342,187 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
   }
 }
 
+// ===========================================================================
+// Packed row-lane sensitivity kernel: several trajectories per wavefront, for SMALL models.
+//
+// The reference's own fixtures have 1 - 2 state variables and 2 - 5 parameters: in the row-lane kernel 3 - 5 of the 64
+// lanes carry equations and every trajectory costs a whole wavefront's issue slots.  Here a wavefront is cut into
+// 64 / SEG segments of SEG = 4, 8, 16 or 32 lanes (SEG >= n_vars and >= n_sens), one trajectory each: lane li of a
+// segment owns sensitivity column li (all NV rows) and state component li.  As in the packed state-only kernel the
+// segments share the instruction stream but not the control flow: time, step size and accept / reject decisions are
+// per-lane values, uniform within a segment; the controller's reductions stay inside a segment and return the same
+// bits in every lane of it (exchange-symmetric DPP / butterfly levels).  A row lane hands its J_y entries to the
+// segment's columns through a per-segment LDS table (a lane cannot name "its" row lane by a literal v_readlane index
+// when the segment base varies) and its J_p entries through the segment's slice of A.  A trajectory's result does not
+// depend on which trajectories share its wavefront (tested bitwise).  Used from 2048 trajectories on
+// (SBM_VARIANT_PACKED forces it).
+// ===========================================================================
+template <int SEG>
+__device__ __forceinline__ float sbm_seg_sumf_any(float v) {
+  v += sbm_dpp<0xb1, 0xf>(v);                              // quad_perm:[1,0,3,2]
+  v += sbm_dpp<0x4e, 0xf>(v);                              // quad_perm:[2,3,0,1]
+  if constexpr (SEG >= 8) v += sbm_dpp<0x141, 0xf>(v);     // row_half_mirror
+  if constexpr (SEG >= 16) v += sbm_dpp<0x140, 0xf>(v);    // row_mirror
+  if constexpr (SEG == 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+template <int SEG>
+__device__ __forceinline__ float sbm_seg_maxf_any(float v) {
+  v = fmaxf(v, sbm_dpp<0xb1, 0xf>(v));
+  v = fmaxf(v, sbm_dpp<0x4e, 0xf>(v));
+  if constexpr (SEG >= 8) v = fmaxf(v, sbm_dpp<0x141, 0xf>(v));
+  if constexpr (SEG >= 16) v = fmaxf(v, sbm_dpp<0x140, 0xf>(v));
+  if constexpr (SEG == 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return v;
+}
+
+template <class M, int SEG>
+struct SbmPackedSensShared {
+  static constexpr int TPW = 64 / SEG;
+  double Y[64];                                   // stage state, segment by segment
+  double JYL[TPW * M::NV * M::RL_MAXJY + 2];      // [segment][row][slot] (+ spare slot)
+  double A[TPW * M::NV * SEG + 2];                // [segment][row][column of the segment] (+ spare slot)
+};
+
+template <class M, int SEG>
+struct PackedRowLaneSystem {
+  static constexpr int NV = M::NV;
+  static constexpr int NVX = M::NV + 1;
+  static constexpr int CPL = 1;
+  static constexpr int NCS = 1;
+  static constexpr bool kUniform = false;
+  __device__ __forceinline__ static constexpr int col_of(int, int) { return 0; }
+  SbmPackedSensShared<M, SEG>* sh;
+  int lane, li, cls;
+  bool has_row, has_col;
+  int yidx[M::RL_MAXYS], jypos[M::RL_MAXJY], apos[M::RL_MAXJP];
+  double ps[M::RL_MAXPS];
+  const double* jyl;        // this segment's J_y table
+  const double* acolp;      // this lane's column of the segment's A: acolp[i * SEG]
+
+  __device__ __forceinline__ static void lds_order() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
+  struct Token { double f; };
+  struct Pending { double ys[M::RL_MAXYS]; };
+  __device__ __forceinline__ Pending issue(double, const double (&z)[1][NVX]) const {
+    Pending p;
+    sh->Y[lane] = z[0][NV];
+    lds_order();
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXYS; ++s) p.ys[s] = sh->Y[yidx[s]];
+    lds_order();
+    return p;
+  }
+  __device__ __forceinline__ Token eval(const Pending& p, double t) const {
+    Token k;
+    double jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+    k.f = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = 0.0;
+    M::class_dispatch(cls, t, p.ys, ps, k.f, jy, jp);
+    k.f = cls >= 0 ? k.f : 0.0;
+    lds_order();
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJP; ++s) sh->A[apos[s]] = jp[s];
+#pragma unroll
+    for (int s = 0; s < M::RL_MAXJY; ++s) sh->JYL[jypos[s]] = jy[s];
+    lds_order();
+    return k;
+  }
+  __device__ __forceinline__ void finish(const Token&, double, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
+    double zc[NV], dc[NV], acol[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { zc[i] = z[0][i]; acol[i] = acolp[i * SEG]; }
+    lds_order();
+    M::apply_lds(jyl, acol, zc, dc);
+    lds_order();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dz[0][i] = dc[i];
+  }
+  __device__ __forceinline__ void extra_out(const Token& k, double (&dz)[1][NVX]) const { dz[0][NV] = k.f; }
+  __device__ __forceinline__ void rhs(double t, const double (&z)[1][NVX], double (&dz)[1][NVX]) const {
+    const Token k = eval(issue(t, z), t);
+    extra_out(k, dz);
+    finish(k, t, z, dz);
+  }
+  __device__ __forceinline__ float norm(const float (&colsum)[1], float xsum) const {
+    const float m = has_col ? sbm_nan_to_inf(colsum[0]) : 0.f;
+    const float x = has_row ? sbm_nan_to_inf(xsum) : 0.f;
+    return sqrtf(fmaxf(sbm_seg_maxf_any<SEG>(m), sbm_seg_sumf_any<SEG>(x)) * (1.0f / NV));
+  }
+  __device__ __forceinline__ double sum(double v) const { return sbm_seg_sum<SEG>(v); }
+};
+
+template <class M, int METHOD, int SEG>
+__global__ void __launch_bounds__(64) sbm_sens_packed_kernel(sbm_kernel_args a) {
+  using Sys = PackedRowLaneSystem<M, SEG>;
+  using Sh = SbmPackedSensShared<M, SEG>;
+  constexpr int NV = M::NV, NVX = NV + 1, NK = M::NK, TPW = 64 / SEG;
+  static_assert(SEG >= 4 && SEG <= 32 && (SEG & (SEG - 1)) == 0 && NV <= SEG && NK <= SEG, "packed sensitivity kernel: a row and a column per lane of a segment");
+  __shared__ Sh sh;
+  const int lane = threadIdx.x;
+  const int seg = lane / SEG, li = lane - seg * SEG;
+  const int traj_raw = (int)blockIdx.x * TPW + seg;
+  const bool live = traj_raw < a.n_traj;            // segments beyond the batch integrate a copy of the last trajectory
+  const int traj = live ? traj_raw : a.n_traj - 1;
+  for (int i = lane; i < TPW * NV * M::RL_MAXJY + 2; i += 64) sh.JYL[i] = 0.0;
+  for (int i = lane; i < TPW * NV * SEG + 2; i += 64) sh.A[i] = 0.0;
+  sh.Y[lane] = 0.0;
+
+  Sys sys;
+  sys.sh = &sh;
+  sys.lane = lane;
+  sys.li = li;
+  sys.has_row = li < NV;
+  sys.has_col = li < NK;
+  const int row = sys.has_row ? li : 0;
+  sys.cls = sys.has_row ? M::rl_class(row) : -1;
+  const double* P = a.P + (size_t)traj * M::NP;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXYS; ++s) sys.yidx[s] = M::rl_ys(s, row) + seg * SEG;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXPS; ++s) sys.ps[s] = P[M::rl_ps(s, row)];
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJY; ++s)
+    sys.jypos[s] = (sys.has_row && M::rl_jycol(s, row) >= 0) ? (seg * NV + row) * M::RL_MAXJY + s : TPW * NV * M::RL_MAXJY + 1;
+#pragma unroll
+  for (int s = 0; s < M::RL_MAXJP; ++s) {
+    const int c = M::rl_jpcol(s, row);
+    sys.apos[s] = (sys.has_row && c >= 0) ? (seg * NV + row) * SEG + c : TPW * NV * SEG + 1;
+  }
+  sys.jyl = sh.JYL + seg * NV * M::RL_MAXJY;
+  sys.acolp = sh.A + seg * NV * SEG + li;
+  __syncthreads();
+
+  const int goff = a.grid_off ? a.grid_off[traj] : 0;
+  const int glen = a.grid_len ? a.grid_len[traj] : a.n_t;
+  const double* tg = a.t_out + goff;
+
+  double z[1][NVX];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) z[0][i] = (a.s0 && sys.has_col) ? a.s0[i * NK + li] : 0.0;
+  z[0][NV] = (a.y0 && sys.has_row) ? a.y0[li] : 0.0;
+
+  double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
+  double* St = a.S ? a.S + (size_t)traj * a.n_t * NV * NK : nullptr;
+  auto store = [&](int io, const double (&zz)[1][NVX]) {
+    if (Yt && sys.has_row && live) Yt[(size_t)io * NV + li] = zz[0][NV];
+    if (St && sys.has_col && live) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + li] = zz[0][i];
+    }
+  };
+  SbmTrajOut r;
+  if constexpr (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
+  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+  if (li == 0 && live) {
+    if (a.status) a.status[traj] = r.status;
+    if (a.n_steps) a.n_steps[traj] = r.n_acc;
+    if (a.n_reject) a.n_reject[traj] = r.n_rej;
+  }
+}
+
 // v[lane] of a per-lane array held in registers: a binary select tree over the bits of `lane`.  The
 // obvious chain of `lane == i` selects makes the compiler keep N loop-invariant 64-bit lane masks in
 // SGPRs (100 of them for N = 50: it spilled them through v_writelane and AGPRs); the tree needs
@@ -1662,6 +1843,17 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
       return (int)hipGetLastError();
     }
   }
+  // small models: several trajectories per wavefront (sbm_sens_packed_kernel)
+  if constexpr (M::NV <= 32 && M::NK <= 32 && M::NV * (M::NK + 1) <= 256) {
+    constexpr int need = M::NV > M::NK ? M::NV : M::NK;
+    constexpr int SEG = need <= 4 ? 4 : (need <= 8 ? 8 : (need <= 16 ? 16 : 32));
+    if (kind == SBM_KIND_SENS && (a.opts.variant == SBM_VARIANT_PACKED || (a.opts.variant == SBM_VARIANT_AUTO && a.n_traj >= 2048))) {
+      dim3 grid((a.n_traj + 64 / SEG - 1) / (64 / SEG)), block(64);
+      if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_packed_kernel<M, SBM_DOPRI45, SEG>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((sbm_sens_packed_kernel<M, SBM_RK4_FIXED, SEG>), grid, block, 0, stream, a);
+      return (int)hipGetLastError();
+    }
+  }
   if (kind == SBM_KIND_SENS) {
     // row-lane / row-group kernels whenever the model fits one row + one column per lane.  Even when
     // every row is a class of its own they evaluate NCLASS <= NV row bodies per stage where the per-wave
@@ -1676,12 +1868,13 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     constexpr bool kPerWaveBuilt = !(kRowGroupOk && M::NV * (M::NK + 1) > 4096);
     const bool rowlane = a.opts.variant == SBM_VARIANT_ROW_LANE ||
                          ((a.opts.variant == SBM_VARIANT_AUTO || a.opts.variant == SBM_VARIANT_SMALL_BATCH ||
-                           a.opts.variant == SBM_VARIANT_MFMA) && kRowLanePays);
+                           a.opts.variant == SBM_VARIANT_MFMA || a.opts.variant == SBM_VARIANT_PACKED) && kRowLanePays);
     // row-group kernel: the row-lane kernel with the rows of a column split over several lanes,
     // when the emitter found a split that cuts the elements per lane (M::RG_OK)
     if constexpr (kRowGroupOk) {
       if (a.opts.variant == SBM_VARIANT_ROW_GROUP || a.opts.variant == SBM_VARIANT_AUTO ||
-          a.opts.variant == SBM_VARIANT_SMALL_BATCH || a.opts.variant == SBM_VARIANT_MFMA || !kPerWaveBuilt) {
+          a.opts.variant == SBM_VARIANT_SMALL_BATCH || a.opts.variant == SBM_VARIANT_MFMA ||
+          a.opts.variant == SBM_VARIANT_PACKED || !kPerWaveBuilt) {
         // Two splits of the same form (emit_rowgroup.py): RG0 for throughput; RG1 -- more, smaller column chunks,
         // fewer elements per lane -- while its wavefronts still find an empty SIMD each (1024 of them): a single
         // parameter vector, a serial optimiser's call, is latency-bound and extra wavefronts are free.

@@ -198,5 +198,17 @@ def emit_rowlane_members(spec, d, meta, make_printer):
                 r, k = where[e_idx]
                 expr = "fma(SBM_LANE_BCAST(jy[%d], %d), z[%d], %s)" % (k, r, c, expr)
         L.append("    dz[%d] = %s;" % (i, expr))
+    L += ["  }", "",
+          "  // the same product with the J_y entries read from a table jyl[row * RL_MAXJY + slot] (LDS): the form of the",
+          "  // packed kernel, where several trajectories share a wavefront and a lane cannot name its row lane literally",
+          "  template <int NZ>",
+          "  __device__ __forceinline__ static void apply_lds(const double* jyl, const double (&acol)[NV],",
+          "                                                   const double (&z)[NZ], double (&dz)[NZ]) {",
+          "    (void)jyl;"]
+    for i in range(n):
+        expr = "acol[%d]" % i
+        for k, (e_idx, c) in enumerate(d.jy_rows[i]):
+            expr = "fma(jyl[%d], z[%d], %s)" % (i * meta['max_jy'] + k, c, expr)
+        L.append("    dz[%d] = %s;" % (i, expr))
     L += ["  }"]
     return L

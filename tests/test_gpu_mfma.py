@@ -62,3 +62,53 @@ def test_mfma_variant_on_a_densely_coupled_network(zoo):
             tight = lambda v=v: oo.tight_solution(gm, P[v], t_out, use_c=True, atol=1e-30)[1:]
             check_parity(np.concatenate([Yb[v, 1:], Sb[v, 1:]], axis=1), np.concatenate([Yr[idx], Sr[idx]], axis=1), tight,
                          what='%s vector %d' % (spec.name, v))
+
+
+# ---------------------------------------------------------------------------
+# small models: several trajectories per wavefront (SBM_VARIANT_PACKED, sbm_sens_packed_kernel)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('name,file', [('simple', 'simple_ref.npz'), ('michaelis_menten', 'mm_ref.npz')])
+@pytest.mark.parametrize('method,kw', [('dopri45', {}), ('rk4', {'n_steps': 16384})])
+def test_packed_sensitivity_kernel_on_the_reference_fixtures(gpu_models, golden, name, file, method, kw):
+    m = gpu_models(name)
+    g = golden(file)
+    rng = np.random.default_rng(4)
+    P = np.concatenate([g['P'], g['P'][:1] * np.exp(0.3 * rng.standard_normal((21, g['P'].shape[1])))])   # 23 vectors: ragged last wave
+    t = g['t'][::37]
+    Sa, Ya = m.calc_jacobian_batch(P, t, return_states=True, method=method, variant='row_lane', **kw)
+    na = m.last_info['n_steps'].copy()
+    Sb, Yb = m.calc_jacobian_batch(P, t, return_states=True, method=method, variant='packed', **kw)
+    assert m.last_info['status'].tolist() == [0] * 23
+    assert np.all(np.abs(m.last_info['n_steps'] - na) <= 2)
+    assert np.allclose(Ya, Yb, rtol=1e-9, atol=1e-12) and np.allclose(Sa, Sb, rtol=1e-9, atol=1e-11)
+    if method == 'dopri45':
+        S2, Y2 = m.calc_jacobian_batch(g['P'], g['t'], return_states=True, variant='packed')      # the golden grid
+        assert parity_err(Y2, g['Y']) <= 1.0 and parity_err(S2, g['S']) <= 1.0
+    # a trajectory's numbers do not depend on who shares its wavefront (bitwise), nor on initial conditions of others
+    mates = np.concatenate([P[:1], P[5:6].repeat(6, axis=0), P[9:10]])
+    Sc = m.calc_jacobian_batch(mates, t, method=method, variant='packed', **kw)
+    assert np.array_equal(Sc[0], Sb[0]) and np.array_equal(Sc[1], Sb[5]) and np.array_equal(Sc[7], Sb[9])
+    # failures stay per trajectory
+    import warnings
+    bad = P[:9].copy()
+    bad[4, 0] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Sd = m.calc_jacobian_batch(bad, t, method=method, variant='packed', **kw)
+    assert m.last_info['status'][4] != 0 and np.all(np.isnan(Sd[4, -1]))
+    ok = [0, 1, 2, 3, 5, 6, 7, 8]
+    assert m.last_info['status'][ok].tolist() == [0] * 8 and np.array_equal(Sd[ok], Sb[ok])
+
+
+def test_packed_kernel_is_what_large_batches_of_small_models_run(gpu_models, golden):
+    """AUTO from 2048 trajectories on: same numbers as the forced variant."""
+    m = gpu_models('michaelis_menten')
+    g = golden('mm_ref.npz')
+    rng = np.random.default_rng(6)
+    P = g['P'][:1] * np.exp(0.2 * rng.standard_normal((2048, 5)))
+    t = np.linspace(0, 100, 6)
+    Sa = m.calc_jacobian_batch(P, t)
+    Sb = m.calc_jacobian_batch(P, t, variant='packed')
+    assert np.array_equal(Sa, Sb)
+    Sc = m.calc_jacobian_batch(P[:64], t, variant='packed')
+    assert np.array_equal(Sc, Sb[:64])
