@@ -727,7 +727,13 @@ class Project(object):
         leastsq(project.residuals, x0, Dfun=project.calc_project_jacobian)): one parameter vector leaves the chip
         empty, so the sensitivity kernel takes its small-batch split unless the project's options name a variant.
         Results equal the corresponding row of a batch call to the integration tolerance, not bit for bit."""
-        return {} if 'variant' in self._options() else {'variant': 'small_batch'}
+        o = self._options()
+        kw = {} if 'variant' in o else {'variant': 'small_batch'}
+        # ... and a stiff trial point must not come back as inf rows where the reference's LSODA would integrate it:
+        # method='auto' (OdeModel._single_method) unless the options name a method of their own
+        if 'method' not in self.integrator_options and hasattr(self._model, '_single_method'):
+            kw.update(self._model._single_method())
+        return kw
 
     def residuals(self, project_param_vector):
         """(B*sim - data)/sigma for every measurement row, then prior rows; (m,) array."""

@@ -380,3 +380,25 @@ def test_graded_first_step_for_inconsistent_initial_conditions():
         tight = lambda v=v: oo.tight_solution(gm, P[v], t_out, use_c=True)[1:]
         check_parity(np.concatenate([Y_c[v, 1:], S_c[v, 1:]], axis=1), np.concatenate([Yr[v], Sr[v]], axis=1), tight,
                      what='binding motif, vector %d' % v, criterion='parity')
+
+
+def test_single_vector_methods_integrate_a_stiff_vector_under_default_options(gpu_models, golden):
+    """The reference's LSODA integrates a stiff parameter vector like any other (it switches to BDF by itself,
+    model/ode_model.py:122-123).  The reference-named single-vector methods -- what a serial optimiser calls -- do too:
+    with DEFAULT options a stiff vector goes through method='auto' and comes back finite and at parity, not as NaN."""
+    m = gpu_models('stiff50')
+    g, gt = golden('stiff50_ref.npz'), golden('stiff50_tight.npz')
+    assert m.integrator_options['method'] == 'dopri45'              # the default; nothing was configured
+    t_out = _from_zero(g['t'][g['idx']])
+    y = m.simulate(g['P'][1], t_out)
+    assert m.last_info['status'].tolist() == [0] and m.last_info['stiff'].tolist() == [True]
+    check_parity(y[1:], g['Y'][1], gt['Y'][1], what='simulate, stiff vector', criterion='parity')
+    s = m.calc_jacobian(g['P'][1], t_out, np.zeros(50 + 2500))
+    assert m.last_info['status'].tolist() == [0] and np.all(np.isfinite(s))
+    check_parity(s[1:], g['S'][1], gt['S'][1], what='calc_jacobian, stiff vector', criterion='parity')
+    # a mild vector of the same model stays on DOPRI45, bit for bit
+    mild = g['P'][0].copy()
+    mild[:50] = 10.0 ** np.linspace(0.0, 1.0, 50)
+    y2 = m.simulate(mild, t_out)
+    assert m.last_info['stiff'].tolist() == [False]
+    assert np.array_equal(y2, m.simulate_batch(mild[None, :], t_out)[0])
