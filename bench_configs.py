@@ -250,7 +250,7 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
     from sysbio_modeling_amd import models_zoo
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        proj, th0 = models_zoo.cascade_config4_project(model, noise=0.0, reference_compat=False)
+        proj, th0 = models_zoo.cascade_config4_project(model, reference_compat=False)     # 5 % noise: the cost has a floor
     n_starts = 256
     starts = th0[None, :] + 0.15 * np.random.default_rng(1).standard_normal((n_starts, th0.size))
     proj.fit_batch(starts[:8], max_iter=3)            # warm-up (scratch allocation)
@@ -258,13 +258,13 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
     best = None
     for _ in range(max(1, reps)):
         t0 = time.perf_counter()
-        fit = proj.fit_batch(starts, max_iter=40)
+        fit = proj.fit_batch(starts, max_iter=100, ftol=1.49012e-8, xtol=1.49012e-8)     # leastsq's default tolerances
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     out = {"workload": "multi-start least-squares fit of the configs[3] project (8 experiments, 512 residual rows, "
-                       "68 parameters, noise-free data): %d starts at 0.15 log-units from the optimum, "
-                       "Project.fit_batch, max 40 iterations" % n_starts,
+                       "68 parameters, 5 %% noise): %d starts at 0.15 log-units from the generating parameters, "
+                       "Project.fit_batch, max 100 iterations" % n_starts,
            "seconds": best, "fits_per_s": n_starts / best, "starts": n_starts,
            "converged": int(fit['converged'].sum()), "cost_median": float(np.median(fit['cost'])),
            "cost_max": float(np.max(fit['cost'])), "evaluations": int(fit['n_evaluations']),
@@ -277,25 +277,45 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
                            dict(proj._measurement_to_model_map_raw),
                            sf_groups=['s%d' % v for v in models_zoo.CASCADE_MEASURED_SPECIES], reference_compat=False)
         calls = [0, 0]
+        best_x = [starts[0].copy(), np.inf]
+        budget_s = 30.0
+
+        class _OutOfTime(Exception):
+            pass
 
         def res(x):
+            if time.perf_counter() - t0 > budget_s:
+                raise _OutOfTime()       # (a trial point that makes the model stiff costs LSODA seconds: bound the leg)
             calls[0] += 1
-            return po.residuals(x)
+            r = po.residuals(x)
+            c0 = 0.5 * float(np.sum(r ** 2))
+            if c0 < best_x[1]:
+                best_x[0], best_x[1] = np.array(x, copy=True), c0
+            return r
 
         def jac(x):
+            if time.perf_counter() - t0 > budget_s:
+                raise _OutOfTime()
             calls[1] += 1
             return po.calc_project_jacobian(x)
         t0 = time.perf_counter()
-        x, _, info, _, ier = leastsq(res, starts[0], Dfun=jac, full_output=True, maxfev=60)
+        try:
+            x, _, info, _, ier = leastsq(res, starts[0], Dfun=jac, full_output=True, maxfev=400)
+        except _OutOfTime:
+            x, ier = best_x[0], -1       # stopped by the time budget: best point so far
         dt = time.perf_counter() - t0
+        t0 = time.perf_counter() + 1e9   # (the cost evaluation below is not part of the budget)
         out["cpu_baseline"] = {
             "value": 1.0 / dt, "unit": "fits/s", "cores": 1, "kind": "port",
-            "sample": "ONE start (#0): scipy.optimize.leastsq(residuals, x0, Dfun=calc_project_jacobian, maxfev=60) "
-                      "over the CPU oracle; %.1f s, %d residual + %d Jacobian evaluations, ier=%d"
+            "sample": "ONE start (#0): scipy.optimize.leastsq(residuals, x0, Dfun=calc_project_jacobian, maxfev=400) "
+                      "over the CPU oracle, stopped after 30 s if not converged (ier = -1); %.1f s, %d residual + %d Jacobian "
+                      "evaluations, ier=%d"
                       % (dt, calls[0], calls[1], ier),
             "cost": float(0.5 * np.sum(res(x) ** 2)),
-            "distance_to_truth": float(np.max(np.abs(x - th0))),
-            "distance_to_gpu_optimum_of_same_start": float(np.max(np.abs(x - fit['theta'][0])))}
+            "gpu_cost_of_same_start": float(fit['cost'][0]),
+            "distance_to_gpu_optimum_of_same_start": float(np.max(np.abs(x - fit['theta'][0]))),
+            "note": "the problem is sloppy (68 parameters, many barely constrained by 512 rows): optima are compared "
+                    "by their COST; parameter vectors of equal cost lie far apart along the sloppy directions"}
         out["speedup_vs_one_core"] = out["fits_per_s"] / out["cpu_baseline"]["value"]
     return out
 

@@ -17,14 +17,15 @@ from .. import _lib
 
 
 def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambda_up=4.0, lambda_down=3.0,
-                              ftol=1e-10, xtol=1e-10, max_step=2.0, **integrator_overrides):
+                              ftol=1.49012e-8, xtol=1.49012e-8, max_step=2.0, **integrator_overrides):
     """Minimise 0.5 |r(theta)|^2 from every row of ``thetas0`` (V, q), independently.
 
     Marquardt damping per start: a step is accepted when the cost decreases (lambda /= lambda_down),
     rejected otherwise (lambda *= lambda_up).  (Nielsen's gain-ratio update was tried and did no better on
     the sloppy 68-parameter test problem.)  A start has converged when a lightly damped (lambda <= 1)
     accepted step lowers the cost by less than ftol * cost with a predicted decrease just as small, or
-    changes no parameter by more than xtol * (|theta| + xtol).
+    changes no parameter by more than xtol * (|theta| + xtol); the defaults are scipy.optimize.leastsq's (the reference's
+    optimiser, tests/test_Project.py:202-213).
     Failed integrations (inf cost) count as rejections.  Two safeguards keep wild trial points from
     stalling the whole batch (one launch waits for its slowest trajectory): every component of a step is
     clipped to ``max_step`` log-units, and trial integrations get a step budget
