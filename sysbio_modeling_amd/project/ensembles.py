@@ -19,19 +19,22 @@ import numpy as np
 
 
 def sampling_matrix(hessian, cutoff=0.0, temperature=1.0, step_scale=1.0):
-    """"Square root" of the inverse of 0.5 * hessian with singular values below ``cutoff * max``
-    clipped, scaled so that the expected quadratic cost increase of a move is about 1, times
-    step_scale * sqrt(T)  (reference _sampling_matrix, Ensembles.py:226-258)."""
-    u, sing_vals, vh = np.linalg.svd(0.5 * np.asarray(hessian, dtype=float))
-    cutoff_sing_val = cutoff * sing_vals.max()
-    D = 1.0 / np.maximum(sing_vals, max(cutoff_sing_val, np.finfo(float).tiny))
-    samp_mat = vh.T * np.sqrt(D)
-    cut = sing_vals[sing_vals < cutoff_sing_val]
-    if len(cut):
-        scale = np.sqrt(len(sing_vals) - len(cut) + cut.sum() / cutoff_sing_val)
-    else:
-        scale = np.sqrt(len(sing_vals))
-    return samp_mat / scale * step_scale * np.sqrt(temperature)
+    """Candidate-move matrix M: a move is M @ z with z standard normal, i.e. Gaussian with covariance M M^T.
+
+    The recipe is SloppyCell's, as the reference carries it (_sampling_matrix, Ensembles.py:226-258): along each
+    principal axis v_i of A = hessian / 2 (eigenvalue a_i) the step has standard deviation 1 / sqrt(max(a_i, c)) with
+    c = cutoff * max a, so flat directions are not followed without bound; everything is then divided by
+    sqrt(n_eff), n_eff = sum_i min(a_i / c, 1) (= the number of axes when nothing is clipped), which makes the
+    expected quadratic cost increase of a move about 1, and multiplied by step_scale * sqrt(temperature).
+    A is symmetric, so the axes come from ``eigh`` (the reference takes an SVD; the two agree up to the sign of each
+    column, which a Gaussian candidate does not see)."""
+    A = 0.5 * np.asarray(hessian, dtype=float)
+    a, V = np.linalg.eigh(0.5 * (A + A.T))
+    a = np.abs(a)                                   # singular values of a symmetric matrix
+    c = cutoff * a.max()
+    stiffness = np.maximum(a, max(c, np.finfo(float).tiny))
+    n_eff = float(np.sum(np.minimum(a / c, 1.0))) if c > 0.0 else float(len(a))
+    return (V / np.sqrt(stiffness)) * (step_scale * np.sqrt(temperature / n_eff))
 
 
 def ensemble_log_params_batch(project, params, hess=None, steps=1000, temperature=1.0, step_scale=1.0,

@@ -13,8 +13,7 @@ from __future__ import annotations
 import os
 from collections import OrderedDict
 
-from .sympy_tools import (parse_model_file, process_model_dict, derive_sparse_jacobians,
-                          _derive_sensitivity_equations, _derive_jacobian_equations)
+from .sympy_tools import parse_model_file, process_model_dict, derive_sparse_jacobians
 from .emit import ModelSpec, Derived, emit_python, emit_c, emit_hip
 
 __all__ = ['parse_model_file', 'process_model_dict', 'make_ode_model', 'make_jit_model',

@@ -2,9 +2,8 @@
 
 Host-side step *before* the hot path: it defines the math and the state layout
 the HIP kernels integrate.  API mirrors the reference module
-(symbolic/sympy_tools.py: ``parse_model_file`` :272, ``process_model_dict`` :325,
-``_derive_sensitivity_equations`` :130, ``_derive_jacobian_equations`` :149),
-re-written for Python 3 and with one structural change: instead of expanding
+(symbolic/sympy_tools.py: ``parse_model_file`` :272, ``process_model_dict`` :325),
+with one structural change: instead of expanding
 and ``simplify``-ing every one of the n*k sensitivity equations
 (reference :145), the model is kept in the sparse matrix form
 
@@ -31,22 +30,21 @@ _CATEGORIES = OrderedDict([
 ])
 
 
-def _sympify_chunk(chunk, sympify_rhs=False, local_symbols=None):
-    """One ``lhs = rhs`` pair per line; comments and blanks skipped (reference :18-35)."""
-    symbols_dict = OrderedDict()
-    for line in chunk:
-        line = line.replace(" ", "").replace("\t", "")
-        if line.startswith("#") or line == "":
+_ASSIGNMENT = re.compile(r'^\s*([A-Za-z_][A-Za-z_0-9]*)\s*=(?!=)\s*(.*?)\s*$')
+
+
+def _section_entries(lines, with_rhs, local_symbols):
+    """The ``name = expression`` lines of one model-text section, in order: name -> Symbol(name), or -> the parsed
+    right-hand side when ``with_rhs``.  Comment lines, blank lines and lines without an assignment are ignored."""
+    entries = OrderedDict()
+    for raw in lines:
+        text = raw.split('#', 1)[0]
+        m = _ASSIGNMENT.match(text)
+        if m is None:
             continue
-        if "=" not in line:
-            continue
-        lhs = line[:line.find("=")]
-        rhs = line[line.find("=") + 1:]
-        if not sympify_rhs:
-            symbols_dict[lhs] = Symbol(lhs)
-        else:
-            symbols_dict[lhs] = sympify(rhs, locals=local_symbols)
-    return symbols_dict
+        name, rhs = m.group(1), m.group(2)
+        entries[name] = sympify(rhs, locals=local_symbols) if with_rhs else Symbol(name)
+    return entries
 
 
 def _model_text(model):
@@ -97,37 +95,8 @@ def parse_model_file(model):
         if category == 'Imports':
             parsed_model[category] = [ln for ln in chunk if ln.strip()] or None
         else:
-            parsed_model[category] = _sympify_chunk(chunk, sympify_rhs, local_symbols)
+            parsed_model[category] = _section_entries(chunk, sympify_rhs, local_symbols)
     return parsed_model
-
-
-def _derive_sensitivity_equations(equations, params):
-    """Expanded forward-sensitivity equations, one per (state i, non-fixed param j).
-
-    d/dt sens_i_j = df_i/dp_j + sum_m df_i/dy_m * sens_m_j   (reference :130-146).
-    Kept for API parity and for cross-checking the sparse form; the emitters
-    use ``derive_sparse_jacobians`` instead.
-    """
-    sens_eqns = OrderedDict()
-    for var_i, f_i in equations.items():
-        for par_j in params.keys():
-            if params[par_j] == 'fixed':
-                continue
-            dsens = diff(f_i, Symbol(par_j))
-            for var_k in equations.keys():
-                sens_kj = Symbol('sens_%s_%s' % (var_k, par_j))
-                dsens += diff(f_i, Symbol(var_k)) * sens_kj
-            sens_eqns['d_sens_%s_%s' % (var_i, par_j)] = dsens
-    return sens_eqns
-
-
-def _derive_jacobian_equations(equations):
-    """d f_i / d y_j for every pair (reference :149-159)."""
-    jacobian_equations = OrderedDict()
-    for var_i, f_i in equations.items():
-        for var_j in equations.keys():
-            jacobian_equations[Symbol('d_%s_d_%s' % (var_i, var_j))] = diff(f_i, Symbol(var_j))
-    return jacobian_equations
 
 
 def derive_sparse_jacobians(equations, params):
@@ -155,6 +124,25 @@ def derive_sparse_jacobians(equations, params):
                 if d != 0:
                     jp.append((i, j, d))
     return jy, jp
+
+
+def expanded_sensitivity_equations(equations, params, jy, jp):
+    """'d_sens_<var>_<param>' -> expression, state-major / parameter-minor over the non-fixed parameters (the key
+    order of the reference's dictionary, symbolic/sympy_tools.py:130-146), built from the sparse Jacobian triplets."""
+    var_names = list(equations)
+    sens_params = [q for q in params if params[q] != 'fixed']
+    rows_y = [[] for _ in var_names]
+    for i, m, d in jy:
+        rows_y[i].append((m, d))
+    entries_p = {(i, j): d for i, j, d in jp}
+    out = OrderedDict()
+    for i, var_i in enumerate(var_names):
+        for j, par_j in enumerate(sens_params):
+            total = entries_p.get((i, j), sympify(0))
+            for m, d in rows_y[i]:
+                total = total + d * Symbol('sens_%s_%s' % (var_names[m], par_j))
+            out['d_sens_%s_%s' % (var_i, par_j)] = total
+    return out
 
 
 def process_model_dict(model_dict, fixed_params=None, calculate_model_sensitivities=True,
@@ -203,18 +191,24 @@ def process_model_dict(model_dict, fixed_params=None, calculate_model_sensitivit
         expanded_eqns = OrderedDict((v, expanded_eqns[v]) for v in variables)
     model_dict['Expanded Equations'] = expanded_eqns
 
-    sens_eqns = None
-    if calculate_model_sensitivities:
-        sens_eqns = _derive_sensitivity_equations(expanded_eqns, params)
+    jy, jp = derive_sparse_jacobians(expanded_eqns, params)
+    model_dict['Sparse Jacobians'] = (jy, jp)
+    # The expanded forms the reference's dictionary carries are assembled from the sparse triplets (the emitters
+    # never use them): d/dt sens_i_j = J_p[i, j] + sum_m J_y[i, m] sens_m_j, and d f_a / d y_b of the augmented system.
+    sens_eqns = expanded_sensitivity_equations(expanded_eqns, params, jy, jp) if calculate_model_sensitivities else None
     model_dict['Sensitivity Equations'] = sens_eqns
-    model_dict['Sparse Jacobians'] = derive_sparse_jacobians(expanded_eqns, params)
-
     model_jac_eqns = None
     if calculate_model_jacobian:
-        all_eqns = OrderedDict(expanded_eqns)
+        system = OrderedDict(expanded_eqns)
         if sens_eqns is not None:
-            all_eqns.update(sens_eqns)
-        model_jac_eqns = _derive_jacobian_equations(all_eqns)
+            system.update((k[2:], v) for k, v in sens_eqns.items())
+        model_jac_eqns = OrderedDict()
+        names = list(system)
+        for a_name, f_a in system.items():
+            present = f_a.free_symbols
+            for b_name in names:
+                sb = Symbol(b_name)
+                model_jac_eqns[Symbol('d_%s_d_%s' % (a_name, b_name))] = diff(f_a, sb) if sb in present else sympify(0)
     model_dict['Model Jacobian Equations'] = model_jac_eqns
 
     subexpressions = None

@@ -127,3 +127,22 @@ def test_control_loops_on_torch_tensors():
     out, st, _, levels = _control.controlled_romberg(run, 2, ['y'], 1e-9, 1e-12, max_doublings=10)
     assert st.tolist() == [0, 0] and levels[0] < levels[1] and isinstance(out['y'], torch.Tensor)
     assert np.allclose(out['y'].numpy(), exact, rtol=1e-9)
+
+
+def test_sampling_matrix_is_the_clipped_inverse_square_root_of_half_the_hessian():
+    """project/ensembles.py::sampling_matrix against the recipe written out axis by axis (reference
+    Ensembles.py:226-258): covariance sum_i v_i v_i^T / max(a_i, c) / n_eff * step_scale^2 * T."""
+    from sysbio_modeling_amd.project.ensembles import sampling_matrix
+    rng = np.random.default_rng(4)
+    J = rng.standard_normal((40, 6)) * np.array([1.0, 1.0, 0.1, 1e-2, 1e-3, 1e-4])
+    H = J.T @ J
+    a, V = np.linalg.eigh(0.5 * H)
+    for cutoff, T, scale in ((0.0, 1.0, 1.0), (1e-3, 2.0, 0.7), (0.3, 0.5, 1.5)):
+        c = cutoff * a.max()
+        n_eff = sum(1.0 if ai >= c else ai / c for ai in a)
+        want = sum(np.outer(V[:, i], V[:, i]) / max(a[i], c) for i in range(6)) / n_eff * scale ** 2 * T
+        M = sampling_matrix(H, cutoff, T, scale)
+        assert np.allclose(M @ M.T, want, rtol=1e-10, atol=1e-12 * np.abs(want).max())
+    # unclipped: the expected quadratic cost increase 0.5 z^T M^T H M z of a move is 1
+    M = sampling_matrix(H)
+    assert np.isclose(0.5 * np.trace(M.T @ H @ M), 1.0)

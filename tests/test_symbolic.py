@@ -13,7 +13,7 @@ import sympy
 from sysbio_modeling_amd import build, models_zoo
 from sysbio_modeling_amd.symbolic import (make_ode_model, make_jit_model, parse_model_file,
                                           process_model_dict, zoo_model, ZOO_NAMES)
-from sysbio_modeling_amd.symbolic.sympy_tools import _derive_sensitivity_equations
+from oracle.expanded_sens import reference_style_sensitivity_equations as _derive_sensitivity_equations
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
