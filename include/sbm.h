@@ -34,6 +34,9 @@ typedef struct sbm_ctx sbm_ctx;
 typedef struct sbm_model sbm_model;
 typedef struct sbm_project sbm_project;
 
+/* the implicit kernels keep a column of the sensitivity matrix per lane in registers */
+#define SBM_IMPLICIT_MAX_NV 128
+
 /* integrators.  The reference always uses LSODA at rtol = atol = 1e-10
  * (model/ode_model.py:122-123,167-168); these are the GPU replacements. */
 enum {
@@ -43,8 +46,8 @@ enum {
    * the model generator worked out for the model's Jacobian pattern; the sensitivities are
    * the exact derivative of the scheme (one linear solve per column with the matrix Newton
    * just factored).  Second order, symmetric: the error expands in h^2, so two runs with
-   * step_mult 1 and 2 extrapolate to fourth order.  Needs n_vars <= 64 (any n_sens: one
-   * wavefront per 64 sensitivity columns).                                                   */
+   * step_mult 1 and 2 extrapolate to fourth order.  Needs n_vars <= SBM_IMPLICIT_MAX_NV
+   * (state component i lives on lane i mod 64; any n_sens: one wavefront per 64 columns).    */
   SBM_IMPLICIT_MIDPOINT = 2,
   /* The same with a graded first step, cut into 13 midpoint substeps of sizes
    * h0 * 2^-12, 2^-12, 2^-11, ..., 1/2: for initial conditions off a fast manifold -- the

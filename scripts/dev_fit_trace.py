@@ -1,0 +1,31 @@
+"""Iteration-by-iteration trace of Project.fit_batch on the configs[3] project (GPU box): accepted steps, damping,
+cost decrease -- what the convergence tests of levenberg_marquardt_batch see."""
+import sys
+import warnings
+
+import numpy as np
+
+sys.path.insert(0, '.')
+from sysbio_modeling_amd import models_zoo                      # noqa: E402
+from sysbio_modeling_amd.model import OdeModel                  # noqa: E402
+from sysbio_modeling_amd.symbolic import zoo_model              # noqa: E402
+
+gm = zoo_model('cascade20')
+model = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='cascade20')
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    proj, th0 = models_zoo.cascade_config4_project(model, reference_compat=False)
+starts = th0[None, :] + 0.15 * np.random.default_rng(1).standard_normal((64, th0.size))
+kw = dict(max_iter=int(sys.argv[1]) if len(sys.argv) > 1 else 100)
+fit = proj.fit_batch(starts, trace=True, **kw)
+for h in fit['history']:
+    if h['iteration'] < 12 or h['iteration'] % 8 == 0:
+        print(h)
+print('converged', int(fit['converged'].sum()), 'of', len(starts), 'n_iter', np.bincount(fit['n_iter'])[-5:],
+      'cost min/median/max', fit['cost'].min(), np.median(fit['cost']), fit['cost'].max())
+J = proj.evaluate_batch(fit['theta'][:1], jacobian=True, want=('jacobian',))
+Jm = J['jacobian'][0]
+r = J['residuals'][0]
+g = Jm.T @ r
+sv = np.linalg.svd(Jm, compute_uv=False)
+print('gradient norm at the end', np.linalg.norm(g), 'cost', 0.5 * r @ r, 'singular values of J: max %.3g min %.3g' % (sv[0], sv[-1]))

@@ -19,6 +19,7 @@ SBM_DOPRI45 = 1
 SBM_IMPLICIT_MIDPOINT = 2
 SBM_IMPLICIT_MIDPOINT_GRADED = 3
 SBM_IMPLICIT_ADAPTIVE = 4
+IMPLICIT_MAX_NV = 128     # include/sbm.h: SBM_IMPLICIT_MAX_NV
 STATUS_NAMES = {0: 'ok', 1: 'max_steps', 2: 'non_finite', 3: 'step_underflow', 4: 'newton_fail',
                 5: 'tolerance_not_reached'}
 

@@ -218,9 +218,9 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
 
 static int check_model_fits(const sbm_model* m, const sbm_integrator_opts& o, const char* who) {
   if ((o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED || o.method == SBM_IMPLICIT_ADAPTIVE) &&
-      m->info.n_vars > 64)
-    return sbm_fail(SBM_E_ARG, "%s: the implicit midpoint kernel holds one state variable per lane: n_vars <= 64 "
-                    "(model '%s' has %d)", who, m->info.name, m->info.n_vars);
+      m->info.n_vars > SBM_IMPLICIT_MAX_NV)
+    return sbm_fail(SBM_E_ARG, "%s: the implicit midpoint kernels hold a column of the sensitivity matrix per lane in "
+                    "registers: n_vars <= %d (model '%s' has %d)", who, SBM_IMPLICIT_MAX_NV, m->info.name, m->info.n_vars);
   return 0;
 }
 

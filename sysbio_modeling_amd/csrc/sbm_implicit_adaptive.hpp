@@ -39,8 +39,9 @@
 // trajectory is graded (13 geometric substeps, as SBM_IMPLICIT_MIDPOINT_GRADED; cut again in the finer solutions): the
 // reference always starts from y = 0, possibly off a fast manifold.
 //
-// Mapping: that of sbm_imid_kernel (lane j = column j of S with all NV rows in registers, lane i = state component i,
-// row lanes evaluate f_i / J_y / J_p by class; sparse LU from emit_implicit.py, distributed for triangular patterns).
+// Mapping and the step itself: sbm_implicit_stepper.hpp (lane j = column j of S with all NV rows in registers, state
+// component i on lane i mod 64, row lanes evaluate f_i / J_y / J_p by class; sparse LU from emit_implicit.py,
+// distributed for triangular patterns).
 // Registers: the S columns of the solution being advanced and the solver's work vector b, as in the fixed-step
 // kernel; the other two solutions' columns wait in LDS ([row][column], 2 x 8 NV NKc bytes).  J_p reaches the columns through a compact table
 // (RL_MAXJP values per row, picked by column index) when rows have few parameter entries, through the dense
@@ -50,113 +51,16 @@
 template <class M>
 struct SbmImadShared {
   static constexpr bool A_SPARSE = (M::RL_MAXJP <= 4);
-  double Y[64];                 // iterate, one component per row lane
-  double G[64];                 // Newton residual, one component per row lane
+  static constexpr int NROW = 64 * ((M::NV + 63) / 64);
+  static constexpr int A_SIZE = A_SPARSE ? (M::NV * M::RL_MAXJP + 2) : (M::NV * 64 + 2);
+  double Y[NROW];               // iterate, one component per row lane (rows lane, lane + 64, ...)
+  double G[NROW];               // Newton residual
   double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
   double MF[M::IM_NM + 2];      // IM_TRI: reciprocal pivots and scaled entries, written row by row lane
-  double A[A_SPARSE ? (M::NV * M::RL_MAXJP + 2) : (M::NV * 64 + 2)];   // J_p: [row][slot] or [row][column]
+  double A[A_SIZE];             // J_p: [row][slot] or [row][column]
   static constexpr int ZC = M::NK < 64 ? M::NK : 64;     // columns of a chunk that exist
   static constexpr int ZS = ZC < 64 ? ZC + 1 : 64;       // + one spare column that the idle lanes share (all zeros)
   double ZO[2][M::NV * ZS];     // S of the two solutions that are NOT being advanced at the moment, [row][column]
-};
-
-template <class M>
-struct SbmImadStepper {
-  static constexpr int NV = M::NV;
-  using Sh = SbmImadShared<M>;
-  Sh* sh;
-  int lane, chunk, cls;
-  bool has_row;
-  int yidx[M::RL_MAXYS], jyout[M::RL_MAXJY], apos[M::RL_MAXJP], mfpos[M::RL_MAXJY];
-  int rdpos, diagslot;
-  double ps[M::RL_MAXPS];
-  double m[M::IM_NM];
-
-  __device__ __forceinline__ static void fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
-
-  // Newton on the midpoint state of one step of size 2*hh from y: on entry yb = predictor, on exit the midpoint.
-  // Leaves the factors of M = I - hh J_y (m / sh->MF) and J_p (sh->A) of the last iterate for sens().
-  // Returns SBM_OK, SBM_NEWTON_FAIL or SBM_NON_FINITE (wave-uniform).
-  __device__ __forceinline__ int newton(double tm, double hh, double y, double& yb, double nrtol, double natol,
-                                        int& n_iter) {
-    constexpr int MAXIT = 10;
-    for (int it = 0; it < MAXIT; ++it) {
-      ++n_iter;
-      sh->Y[lane] = yb;
-      fence();
-      double ys[M::RL_MAXYS];
-#pragma unroll
-      for (int q = 0; q < M::RL_MAXYS; ++q) ys[q] = sh->Y[yidx[q]];
-      double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
-#pragma unroll
-      for (int q = 0; q < M::RL_MAXJY; ++q) jy[q] = 0.0;
-#pragma unroll
-      for (int q = 0; q < M::RL_MAXJP; ++q) jp[q] = 0.0;
-      M::class_dispatch(cls, tm, ys, ps, f, jy, jp);
-      fence();
-#pragma unroll
-      for (int q = 0; q < M::RL_MAXJP; ++q) sh->A[apos[q]] = jp[q];
-#pragma unroll
-      for (int q = 0; q < M::RL_MAXJY; ++q) sh->JY[jyout[q]] = jy[q];
-      sh->G[lane] = has_row ? (yb - y) - hh * f : 0.0;
-      if constexpr (M::IM_TRI) {
-        double jd = 0.0;
-#pragma unroll
-        for (int q = 0; q < M::RL_MAXJY; ++q) jd = sbm_sel(diagslot == q, jy[q], jd);
-        const double rd = sbm_rcp(fma(-hh, jd, 1.0));
-        sh->MF[rdpos] = rd;
-#pragma unroll
-        for (int q = 0; q < M::RL_MAXJY; ++q) sh->MF[mfpos[q]] = hh * jy[q] * rd;
-      }
-      fence();
-      double b[NV];
-      if constexpr (M::IM_TRI) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
-        M::im_solve_tri(sh->MF, b);
-        fence();
-      } else {
-        M::im_build(hh, sh->JY, m);
-        M::im_factor(m);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
-        fence();
-        M::im_solve(m, b);
-      }
-      const double d = has_row ? sbm_pick_tree<NV>(b, lane) : 0.0;   // lane i keeps delta_i
-      yb -= d;
-      float r = has_row ? (float)(fabs(d) / fma(nrtol, fabs(yb), natol)) : 0.f;
-      r = sbm_wave_max(sbm_nan_to_inf(r));
-      if (!(r < 3.0e38f)) return SBM_NON_FINITE;
-      if (r <= 1.0f) return SBM_OK;
-    }
-    return SBM_NEWTON_FAIL;
-  }
-
-  // J_p[i][this lane's column]
-  __device__ __forceinline__ double a_of(int i) const {
-    if constexpr (Sh::A_SPARSE) {
-      double a = 0.0;
-#pragma unroll
-      for (int q = 0; q < M::RL_MAXJP; ++q)
-        a = sbm_sel(M::rl_jpcol(q, i) - 64 * chunk == lane, sh->A[i * M::RL_MAXJP + q], a);
-      return a;
-    } else {
-      return sh->A[i * 64 + lane];
-    }
-  }
-
-  // one midpoint step of the sensitivities with the matrices newton() left: z <- 2 M^-1 (z + hh J_p) - z
-  __device__ __forceinline__ void sens(double hh, double (&z)[NV]) {
-    double b[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) b[i] = fma(hh, a_of(i), z[i]);
-    if constexpr (M::IM_TRI) M::im_solve_tri(sh->MF, b);
-    else M::im_solve(m, b);
-    fence();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) z[i] = fma(2.0, b[i], -z[i]);
-  }
 };
 
 template <class M>
@@ -164,52 +68,17 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
   constexpr int NV = M::NV, NK = M::NK;
   constexpr int NCH = (NK + 63) / 64;
   using Sh = SbmImadShared<M>;
-  static_assert(NV <= 64, "implicit kernels: one state row per lane");
+  using Stepper = SbmImplicitStepper<M, Sh>;
+  constexpr int RPL = Stepper::RPL;
   __shared__ Sh sh;
   if ((int)blockIdx.x >= a.n_traj) return;
   const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int lane = threadIdx.x;
   const int chunk = NCH > 1 ? (int)blockIdx.y : 0;
   const int col = lane + 64 * chunk;
-  for (int i = lane; i < (int)(sizeof(sh.A) / sizeof(double)); i += 64) sh.A[i] = 0.0;
-  for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
-  for (int i = lane; i < M::IM_NM + 2; i += 64) sh.MF[i] = 0.0;
-  sh.Y[lane] = 0.0;
-  sh.G[lane] = 0.0;
-
-  SbmImadStepper<M> st;
-  st.sh = &sh;
-  st.lane = lane;
-  st.chunk = chunk;
-  const bool has_row = lane < NV, has_col = col < NK;
-  st.has_row = has_row;
-  const int row = has_row ? lane : 0;
-  st.cls = has_row ? M::rl_class(row) : -1;
-  const double* P = a.P + (size_t)traj * M::NP;
-  constexpr int ASPARE = (int)(sizeof(sh.A) / sizeof(double)) - 1;
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXYS; ++s) st.yidx[s] = M::rl_ys(s, row);
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXPS; ++s) st.ps[s] = P[M::rl_ps(s, row)];
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXJY; ++s) st.jyout[s] = has_row ? M::rl_jyout(s, row) : M::NJY + 1;
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXJP; ++s) {
-    if constexpr (Sh::A_SPARSE) {
-      st.apos[s] = has_row ? row * M::RL_MAXJP + s : ASPARE;
-    } else if constexpr (NCH == 1) {
-      st.apos[s] = has_row ? M::rl_apos(s, row) : ASPARE;
-    } else {
-      const int lc = M::rl_jpcol(s, row) - 64 * chunk;
-      st.apos[s] = (has_row && lc >= 0 && lc < 64) ? row * 64 + lc : ASPARE;
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXJY; ++s) st.mfpos[s] = (M::IM_TRI && has_row) ? M::im_mfpos(s, row) : M::IM_NM + 1;
-  st.rdpos = (M::IM_TRI && has_row) ? M::im_rstart(row) : M::IM_NM + 1;
-  st.diagslot = (M::IM_TRI && has_row) ? M::im_diagslot(row) : -1;
-#pragma unroll
-  for (int e = 0; e < M::IM_NM; ++e) st.m[e] = 0.0;
+  const bool has_col = col < NK;
+  Stepper st;
+  st.setup(&sh, lane, chunk, a.P + (size_t)traj * M::NP);
   __syncthreads();
 
   const int goff = a.grid_off ? a.grid_off[traj] : 0;
@@ -220,7 +89,7 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
   // the three solutions: index 0 = steps H, 1 = H/2, 2 = H/4.  One of them is "active" (state component in ya, S
   // columns in za), the other two wait in sh.ZO / yw.
   double za[NV];
-  double yw[3] = {0.0, 0.0, 0.0};
+  double yw[3][RPL];            // this lane's state components (rows lane, lane + 64, ...) of the three solutions
   constexpr int ZS = Sh::ZS;
   const int zl = lane < Sh::ZC ? lane : ZS - 1; // idle lanes (beyond the chunk's columns) share the spare column: all zeros
   double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
@@ -244,8 +113,9 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
       sh.ZO[0][i * ZS + zl] = za[i];
       sh.ZO[1][i * ZS + zl] = za[i];
     }
-    const double y_init = (a.y0 && has_row) ? a.y0[lane] : 0.0;
-    yw[0] = yw[1] = yw[2] = y_init;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r)
+      yw[0][r] = yw[1][r] = yw[2][r] = (a.y0 && st.has_row[r]) ? a.y0[lane + 64 * r] : 0.0;
     // who is where: active solution, and which solution each LDS slot holds.  The steps run 0, 1, 2 then 2, 1, 0
     // then 0, 1, 2 ...: two exchanges with LDS per coarse step instead of three.
     int active = 0, slot0 = 1, slot1 = 2;
@@ -255,7 +125,9 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
     int rc = SBM_OK;
     long long n_pass = 0;
     bool first_step = true, abandoned = false, forward = true;
-    double dyp[3] = {0.0, 0.0, 0.0};   // previous increment of each solution over a coarse step: Newton predictors
+    double dyp[3][RPL];                // previous increment of each solution over a coarse step: Newton predictors
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) dyp[0][r] = dyp[1][r] = dyp[2][r] = 0.0;
     double H_prev = 0.0;
     int io = 0;
     for (; io < glen && rc == SBM_OK && !abandoned; ++io) {
@@ -266,10 +138,14 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
         const int n = nd < 1.0 ? 1 : (nd > 2.0e9 ? 2000000000 : (int)nd);
         if (n_acc + n_rej + n_pass + n > max_steps) { rc = SBM_MAX_STEPS; break; }
         const double H = dt / n;
-        const float ymax = sbm_wave_max(has_row ? (float)fabs(yw[2]) : 0.f);
+        float yloc = 0.f;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) yloc = fmaxf(yloc, st.has_row[r] ? (float)fabs(yw[2][r]) : 0.f);
+        const float ymax = sbm_wave_max(yloc);
         const double natol = fmax(0.03 * atol, 4.0e-16 * (double)ymax);
         const double sc_h = H_prev > 0.0 ? H / H_prev : 0.0;
-        dyp[0] *= sc_h; dyp[1] *= sc_h; dyp[2] *= sc_h;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) { dyp[0][r] *= sc_h; dyp[1][r] *= sc_h; dyp[2][r] *= sc_h; }
         H_prev = H;
         for (int s = 0; s < n && rc == SBM_OK; ++s) {
           const double ts = fma((double)s, H, t);
@@ -291,10 +167,14 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
               active = want;
             }
             if (rc == SBM_OK) {
-              double ya = want == 0 ? yw[0] : (want == 1 ? yw[1] : yw[2]);
-              const double ystart = ya;
               const int parts = 1 << want;
-              double dy_pred = (want == 0 ? dyp[0] : (want == 1 ? dyp[1] : dyp[2])) / parts;
+              double ya[RPL], ystart[RPL], dy_pred[RPL];
+#pragma unroll
+              for (int r = 0; r < RPL; ++r) {
+                ya[r] = want == 0 ? yw[0][r] : (want == 1 ? yw[1][r] : yw[2][r]);
+                ystart[r] = ya[r];
+                dy_pred[r] = (want == 0 ? dyp[0][r] : (want == 1 ? dyp[1][r] : dyp[2][r])) / parts;
+              }
               const int nops = first_step ? (GRADE + 1) * parts : parts;
               double tt = ts;
 #pragma unroll 1
@@ -303,20 +183,31 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
                 if (first_step) {
                   const int gj = k / parts;
                   h = ldexp(H, -(gj == 0 ? GRADE : GRADE - gj + 1)) / parts;
-                  dy_pred = 0.0;
                 }
-                const double y_before = ya;
-                double yb = fma(0.5, dy_pred, ya);
-                rc = st.newton(tt + 0.5 * h, 0.5 * h, ya, yb, nrtol, natol, n_newton);
+                double y_before[RPL], yb[RPL];
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                  if (first_step) dy_pred[r] = 0.0;
+                  y_before[r] = ya[r];
+                  yb[r] = fma(0.5, dy_pred[r], ya[r]);
+                }
+                rc = st.template newton<10>(tt + 0.5 * h, 0.5 * h, ya, yb, nrtol, natol, n_newton);
                 if (rc == SBM_OK) {
-                  ya = fma(2.0, yb, -ya);
+#pragma unroll
+                  for (int r = 0; r < RPL; ++r) ya[r] = fma(2.0, yb[r], -ya[r]);
                   if (with_sens) st.sens(0.5 * h, za);
                 }
-                dy_pred = ya - y_before;      // the next piece starts from this piece's increment
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) dy_pred[r] = ya[r] - y_before[r];   // the next piece starts from this piece's increment
                 tt += h;
               }
-              const double inc = ya - ystart;
-              if (want == 0) { yw[0] = ya; dyp[0] = inc; } else if (want == 1) { yw[1] = ya; dyp[1] = inc; } else { yw[2] = ya; dyp[2] = inc; }
+#pragma unroll
+              for (int r = 0; r < RPL; ++r) {
+                const double inc = ya[r] - ystart[r];
+                if (want == 0) { yw[0][r] = ya[r]; dyp[0][r] = inc; }
+                else if (want == 1) { yw[1][r] = ya[r]; dyp[1][r] = inc; }
+                else { yw[2][r] = ya[r]; dyp[2][r] = inc; }
+              }
             }
           }
           forward = !forward;
@@ -344,16 +235,32 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
           if (St && has_col) St[((size_t)io * NV + i) * NK + col] = t32;
         }
       }
-      const double y32 = fma(yw[2] - yw[1], 1.0 / 3.0, yw[2]), y22 = fma(yw[1] - yw[0], 1.0 / 3.0, yw[1]);
-      const float ymax_now = sbm_wave_max(has_row ? (float)fabs(y32) : 0.f);
-      const float ry = has_row ? (float)((y32 - y22) * (1.0 / 3.0)) *
-                                     __builtin_amdgcn_rcpf((float)fma(rtol, fmax(fabs(y32), 1e-6 * (double)ymax_now), atol)) : 0.f;
-      const float xs = sbm_wave_sumf(sbm_nan_to_inf(ry * ry));
+      double y32[RPL];
+      float yloc = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        y32[r] = fma(yw[2][r] - yw[1][r], 1.0 / 3.0, yw[2][r]);
+        yloc = fmaxf(yloc, st.has_row[r] ? (float)fabs(y32[r]) : 0.f);
+      }
+      const float ymax_now = sbm_wave_max(yloc);
+      float ry2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const double y22 = fma(yw[1][r] - yw[0][r], 1.0 / 3.0, yw[1][r]);
+        const float ry = st.has_row[r] ? (float)((y32[r] - y22) * (1.0 / 3.0)) *
+                                             __builtin_amdgcn_rcpf((float)fma(rtol, fmax(fabs(y32[r]), 1e-6 * (double)ymax_now), atol)) : 0.f;
+        ry2 += sbm_nan_to_inf(ry * ry);
+      }
+      const float xs = sbm_wave_sumf(ry2);
       const float mx = sbm_wave_max(has_col ? sbm_nan_to_inf(cs) : 0.f);
       const float err = sqrtf(fmaxf(mx, xs) * (1.0f / NV));
       if (!(err < 3.0e38f)) { rc = SBM_NON_FINITE; break; }
       err_max = fmaxf(err_max, err);
-      if (Yt && has_row && chunk == 0) Yt[(size_t)io * NV + lane] = y32;
+      if (Yt && chunk == 0) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+          if (st.has_row[r]) Yt[(size_t)io * NV + lane + 64 * r] = y32[r];
+      }
       if (err_max > 16.0f && pass + 1 < MAXPASS) abandoned = true;    // clearly not good enough: do not finish the pass
     }
     complete = rc == SBM_OK && !abandoned;
@@ -378,7 +285,11 @@ __global__ void __launch_bounds__(64) sbm_imid_adaptive_kernel(sbm_kernel_args a
     // a failed trajectory reports NaN rows (the last pass may have written a part of them); one that only missed
     // the tolerance keeps its finest result, as the host loop does (status SBM_TOL_NOT_REACHED)
     for (int io = 0; io < glen; ++io) {
-      if (Yt && has_row && chunk == 0) Yt[(size_t)io * NV + lane] = __builtin_nan("");
+      if (Yt && chunk == 0) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+          if (st.has_row[r]) Yt[(size_t)io * NV + lane + 64 * r] = __builtin_nan("");
+      }
       if (St && has_col) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + col] = __builtin_nan("");

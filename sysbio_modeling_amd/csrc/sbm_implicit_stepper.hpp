@@ -1,0 +1,203 @@
+// sbm_implicit_stepper.hpp -- one implicit-midpoint step on a wavefront: the Newton iteration on the midpoint state and
+// the linear solve that advances a sensitivity column.  Shared by the fixed-step kernel (sbm_imid_kernel) and the
+// error-controlled one (sbm_imid_adaptive_kernel).
+//
+//   y_{n+1} = y_n + h f(ybar),  ybar = (y_n + y_{n+1}) / 2      Newton on ybar:
+//       M(ybar) delta = ybar - y_n - (h/2) f(ybar),  M = I - (h/2) J_y(ybar)
+//   S_{n+1} = 2 Sbar - S_n,     M Sbar = S_n + (h/2) J_p(ybar)   -- the EXACT derivative of the scheme:
+//       one linear solve per sensitivity column with the matrix Newton just factored.
+//
+// Mapping: lane j owns column j (of its chunk of 64) of S, all NV rows in VGPRs.  State component i lives on lane
+// i mod 64: a model with more than 64 state variables gives every lane RPL = ceil(NV / 64) of them (rows lane,
+// lane + 64, ...).  Row lanes evaluate f_i and the J_y / J_p entries of their rows by class (emit_rowlane.py) and
+// publish them in LDS.  M is the same for every lane of the wave: each lane applies the sparse LU the model generator
+// worked out symbolically for the model's sparsity pattern (emit_implicit.py: straight-line code, static indices,
+// fill-in included; for lower-triangular patterns the factors are one reciprocal per ROW, computed by the row's lane
+// and read from the table MF) to its own right-hand side: the Newton residual (picked apart again: the lane of row i
+// keeps delta_i) and its sensitivity column.
+//
+// The shared-memory struct Sh provides: Y[NROW], G[NROW] (NROW = 64 RPL), JY[NJY + 2], MF[IM_NM + 2], A[A_SIZE] and
+// the constants A_SPARSE (J_p stored [row][slot] instead of [row][64 columns]) and A_SIZE (last slot = spare).
+#pragma once
+
+#include <type_traits>
+#include <utility>
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant
+template <class F, int... I>
+__device__ __forceinline__ void sbm_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sbm_static_for(F&& f) {
+  sbm_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// v[LO + lane] for lane < CNT out of a register array: the select tree of sbm_pick_tree over a slice
+template <int N, int LO, int CNT>
+__device__ __forceinline__ double sbm_pick_slice(const double (&v)[N], int lane) {
+  static_assert(LO >= 0 && CNT >= 1 && LO + CNT <= N, "slice");
+  if constexpr (LO == 0 && CNT == N) {
+    return sbm_pick_tree<N>(v, lane);
+  } else {
+    double t[CNT];
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) t[j] = v[LO + j];
+    return sbm_pick_tree<CNT>(t, lane);
+  }
+}
+
+template <class M, class Sh>
+struct SbmImplicitStepper {
+  static constexpr int NV = M::NV;
+  static constexpr int RPL = (NV + 63) / 64;       // state rows per lane
+  static constexpr int NROW = 64 * RPL;
+  static constexpr int ASPARE = Sh::A_SIZE - 1;
+  Sh* sh;
+  int lane, chunk;
+  bool has_row[RPL];
+  int cls[RPL];
+  int yidx[RPL][M::RL_MAXYS], jyout[RPL][M::RL_MAXJY], apos[RPL][M::RL_MAXJP], mfpos[RPL][M::RL_MAXJY];
+  int rdpos[RPL], diagslot[RPL];
+  double ps[RPL][M::RL_MAXPS];
+  double m[M::IM_NM];
+
+  __device__ __forceinline__ static void fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
+
+  // Clears the LDS tables and loads this lane's rows (operand indices, parameters, output positions).  `chunk` = which
+  // 64 columns of S this wavefront advances.  The caller synchronises (one wavefront per block: a fence suffices).
+  __device__ __forceinline__ void setup(Sh* shared, int lane_, int chunk_, const double* P) {
+    sh = shared;
+    lane = lane_;
+    chunk = chunk_;
+    constexpr int NCH = (M::NK + 63) / 64;
+    for (int i = lane; i < Sh::A_SIZE; i += 64) sh->A[i] = 0.0;
+    for (int i = lane; i < M::NJY + 2; i += 64) sh->JY[i] = 0.0;
+    for (int i = lane; i < M::IM_NM + 2; i += 64) sh->MF[i] = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      sh->Y[lane + 64 * r] = 0.0;
+      sh->G[lane + 64 * r] = 0.0;
+      const bool hr = lane + 64 * r < NV;
+      const int row = hr ? lane + 64 * r : 0;
+      has_row[r] = hr;
+      cls[r] = hr ? M::rl_class(row) : -1;
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXYS; ++s) yidx[r][s] = M::rl_ys(s, row);
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXPS; ++s) ps[r][s] = P[M::rl_ps(s, row)];
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXJY; ++s) jyout[r][s] = hr ? M::rl_jyout(s, row) : M::NJY + 1;
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXJP; ++s) {
+        if constexpr (Sh::A_SPARSE) {
+          apos[r][s] = hr ? row * M::RL_MAXJP + s : ASPARE;
+        } else if constexpr (NCH == 1) {
+          apos[r][s] = hr ? M::rl_apos(s, row) : ASPARE;
+        } else {
+          const int lc = M::rl_jpcol(s, row) - 64 * chunk;       // column within this chunk (unused slots: -1)
+          apos[r][s] = (hr && lc >= 0 && lc < 64) ? row * 64 + lc : ASPARE;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < M::RL_MAXJY; ++s) mfpos[r][s] = (M::IM_TRI && hr) ? M::im_mfpos(s, row) : M::IM_NM + 1;
+      rdpos[r] = (M::IM_TRI && hr) ? M::im_rstart(row) : M::IM_NM + 1;
+      diagslot[r] = (M::IM_TRI && hr) ? M::im_diagslot(row) : -1;
+    }
+#pragma unroll
+    for (int e = 0; e < M::IM_NM; ++e) m[e] = 0.0;
+  }
+
+  // Newton on the midpoint state of one step of size 2*hh from y: on entry yb = predictor, on exit the midpoint.
+  // Leaves the factors of M = I - hh J_y (m / sh->MF) and J_p (sh->A) of the last iterate for sens(): within the
+  // Newton tolerance of the converged midpoint.  Returns SBM_OK, SBM_NEWTON_FAIL or SBM_NON_FINITE (wave-uniform).
+  template <int MAXIT>
+  __device__ __forceinline__ int newton(double tm, double hh, const double (&y)[RPL], double (&yb)[RPL], double nrtol,
+                                        double natol, int& n_iter) {
+    for (int it = 0; it < MAXIT; ++it) {
+      ++n_iter;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) sh->Y[lane + 64 * r] = yb[r];
+      fence();
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        double ys[M::RL_MAXYS];
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXYS; ++q) ys[q] = sh->Y[yidx[r][q]];
+        double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJY; ++q) jy[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJP; ++q) jp[q] = 0.0;
+        M::class_dispatch(cls[r], tm, ys, ps[r], f, jy, jp);
+        fence();
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJP; ++q) sh->A[apos[r][q]] = jp[q];
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJY; ++q) sh->JY[jyout[r][q]] = jy[q];
+        sh->G[lane + 64 * r] = has_row[r] ? (yb[r] - y[r]) - hh * f : 0.0;
+        if constexpr (M::IM_TRI) {
+          double jd = 0.0;
+#pragma unroll
+          for (int q = 0; q < M::RL_MAXJY; ++q) jd = sbm_sel(diagslot[r] == q, jy[q], jd);
+          const double rd = sbm_rcp(fma(-hh, jd, 1.0));
+          sh->MF[rdpos[r]] = rd;
+#pragma unroll
+          for (int q = 0; q < M::RL_MAXJY; ++q) sh->MF[mfpos[r][q]] = hh * jy[q] * rd;
+        }
+      }
+      fence();
+      double b[NV];
+      if constexpr (M::IM_TRI) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
+        M::im_solve_tri(sh->MF, b);
+        fence();
+      } else {
+        M::im_build(hh, sh->JY, m);
+        M::im_factor(m);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
+        fence();
+        M::im_solve(m, b);
+      }
+      float rmax = 0.f;
+      sbm_static_for<RPL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        constexpr int CNT = (NV - 64 * r) < 64 ? (NV - 64 * r) : 64;
+        const double d = has_row[r] ? sbm_pick_slice<NV, 64 * r, CNT>(b, lane) : 0.0;   // the lane of row i keeps delta_i
+        yb[r] -= d;
+        rmax = fmaxf(rmax, has_row[r] ? sbm_nan_to_inf((float)(fabs(d) / fma(nrtol, fabs(yb[r]), natol))) : 0.f);
+      });
+      const float rr = sbm_wave_max(rmax);
+      if (!(rr < 3.0e38f)) return SBM_NON_FINITE;
+      if (rr <= 1.0f) return SBM_OK;
+    }
+    return SBM_NEWTON_FAIL;
+  }
+
+  // J_p[i][this lane's column]
+  __device__ __forceinline__ double a_of(int i) const {
+    if constexpr (Sh::A_SPARSE) {
+      double a = 0.0;
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJP; ++q)
+        a = sbm_sel(M::rl_jpcol(q, i) - 64 * chunk == lane, sh->A[i * M::RL_MAXJP + q], a);
+      return a;
+    } else {
+      return sh->A[i * 64 + lane];
+    }
+  }
+
+  // one midpoint step of a sensitivity column with the matrices newton() left: z <- 2 M^-1 (z + hh J_p) - z
+  __device__ __forceinline__ void sens(double hh, double (&z)[NV]) {
+    double b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) b[i] = fma(hh, a_of(i), z[i]);
+    if constexpr (M::IM_TRI) M::im_solve_tri(sh->MF, b);
+    else M::im_solve(m, b);
+    fence();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) z[i] = fma(2.0, b[i], -z[i]);
+  }
+};

@@ -1542,82 +1542,44 @@ __device__ __forceinline__ double sbm_pick_tree(const double (&v)[N], int lane) 
 }
 
 // ===========================================================================
-// Implicit midpoint for stiff systems (BASELINE configs[4]), state + forward sensitivities.
+// Implicit midpoint for stiff systems (BASELINE configs[4]), state + forward sensitivities, FIXED step.
 //
-//   y_{n+1} = y_n + h f(ybar),  ybar = (y_n + y_{n+1}) / 2      Newton on ybar:
-//       M(ybar) delta = ybar - y_n - (h/2) f(ybar),  M = I - (h/2) J_y(ybar)
-//   S_{n+1} = 2 Sbar - S_n,     M Sbar = S_n + (h/2) J_p(ybar)   -- the EXACT derivative of the scheme:
-//       one linear solve per sensitivity column with the matrix Newton just factored.
-// A-stable and symmetric (second order, error expansion in h^2: the host extrapolates two runs).
-//
-// Mapping: the row-lane one.  Lane j owns column j of S (all NV rows in VGPRs) and lane i the state
-// component y_i; row lanes evaluate f_i and the J_y / J_p entries of their row by class and publish them
-// in LDS.  M is the same for every lane of the wave: each lane builds and factors it redundantly with
-// the LU the model generator worked out symbolically for the model's sparsity pattern
-// (emit_implicit.py: straight-line code, static indices, fill-in included) -- for a cascade that is a
-// bidiagonal forward substitution, not a dense 50x50 solve -- then solves its own right-hand side:
-// the Newton residual (picked apart again: lane i keeps delta_i) and its sensitivity column.
-// Fixed step h0 between output times like RK4; opts.rtol / atol are the Newton tolerances.
+// The step itself (Newton on the midpoint, one linear solve per sensitivity column with the factored Newton matrix,
+// the lane mapping, models with more than 64 state variables) is sbm_implicit_stepper.hpp.  A-stable and symmetric
+// (second order, error expansion in h^2: the caller extrapolates two runs, or uses SBM_IMPLICIT_ADAPTIVE, which does
+// that inside the kernel).  Fixed step h0 between output times like RK4; opts.rtol / atol are the Newton tolerances.
 // More than 64 columns: blockIdx.y = chunk of 64 columns, each wavefront repeating the (identical, fixed-step)
 // state iteration for its own columns; chunk 0 stores the state.
 // ===========================================================================
+#include "sbm_implicit_stepper.hpp"
+
 template <class M>
 struct SbmImidShared {
-  double Y[64];                 // iterate, one component per row lane
-  double G[64];                 // Newton residual, one component per row lane
+  static constexpr bool A_SPARSE = false;
+  static constexpr int NROW = 64 * ((M::NV + 63) / 64);
+  static constexpr int A_SIZE = M::NV * 64 + 2;
+  double Y[NROW];               // iterate, one component per row lane (rows lane, lane + 64, ...)
+  double G[NROW];               // Newton residual
   double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
-  double A[M::NV * 64 + 2];     // A[i][c] = J_p[i][c] (+ spare slot)
+  double A[A_SIZE];             // A[i][c] = J_p[i][c] (+ spare slot)
   double MF[M::IM_NM + 2];      // IM_TRI: reciprocal pivots and scaled entries, written row by row lane
 };
 
-// Lower-triangular J_y (feed-forward networks, M::IM_TRI): no elimination is needed, so the "factorisation"
-// is one reciprocal per ROW and runs distributed -- row lane i scales its own row and publishes it in MF --
-// instead of n reciprocals on every lane; the forward substitution then reads MF (wave-uniform).
 template <class M>
 __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   constexpr int NV = M::NV, NK = M::NK;
-  constexpr int MAXIT = 12;
   constexpr int NCH = (NK + 63) / 64;
-  static_assert(NV <= 64, "implicit midpoint kernel: one row per lane");
+  using Stepper = SbmImplicitStepper<M, SbmImidShared<M>>;
+  constexpr int RPL = Stepper::RPL;
   __shared__ SbmImidShared<M> sh;
   if ((int)blockIdx.x >= a.n_traj) return;
   const int traj = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int lane = threadIdx.x;
   const int chunk = NCH > 1 ? (int)blockIdx.y : 0;
   const int col = lane + 64 * chunk;       // this lane's column of S
-  for (int i = lane; i < NV * 64 + 2; i += 64) sh.A[i] = 0.0;
-  for (int i = lane; i < M::NJY + 2; i += 64) sh.JY[i] = 0.0;
-  for (int i = lane; i < M::IM_NM + 2; i += 64) sh.MF[i] = 0.0;
-  sh.Y[lane] = 0.0;
-  sh.G[lane] = 0.0;
-
-  const bool has_row = lane < NV;
   const bool has_col = col < NK;
-  const int row = has_row ? lane : 0;
-  const int cls = has_row ? M::rl_class(row) : -1;
-  const double* P = a.P + (size_t)traj * M::NP;
-  int yidx[M::RL_MAXYS], jyout[M::RL_MAXJY], apos[M::RL_MAXJP];
-  double ps[M::RL_MAXPS];
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXYS; ++s) yidx[s] = M::rl_ys(s, row);
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXPS; ++s) ps[s] = P[M::rl_ps(s, row)];
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXJY; ++s) jyout[s] = has_row ? M::rl_jyout(s, row) : M::NJY + 1;
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXJP; ++s) {
-    if constexpr (NCH == 1) {
-      apos[s] = has_row ? M::rl_apos(s, row) : NV * 64 + 1;
-    } else {
-      const int lc = M::rl_jpcol(s, row) - 64 * chunk;       // column within this chunk (unused slots: -1)
-      apos[s] = (has_row && lc >= 0 && lc < 64) ? row * 64 + lc : NV * 64 + 1;
-    }
-  }
-  int mfpos[M::RL_MAXJY];
-#pragma unroll
-  for (int s = 0; s < M::RL_MAXJY; ++s) mfpos[s] = (M::IM_TRI && has_row) ? M::im_mfpos(s, row) : M::IM_NM + 1;
-  const int rdpos = (M::IM_TRI && has_row) ? M::im_rstart(row) : M::IM_NM + 1;
-  const int diagslot = (M::IM_TRI && has_row) ? M::im_diagslot(row) : -1;
+  Stepper st;
+  st.setup(&sh, lane, chunk, a.P + (size_t)traj * M::NP);
   __syncthreads();
 
   const int goff = a.grid_off ? a.grid_off[traj] : 0;
@@ -1629,7 +1591,12 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   double z[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) z[i] = (a.s0 && has_col) ? a.s0[i * NK + col] : 0.0;
-  double y = (a.y0 && has_row) ? a.y0[lane] : 0.0;
+  double y[RPL], dy_prev[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    y[r] = (a.y0 && st.has_row[r]) ? a.y0[lane + 64 * r] : 0.0;
+    dy_prev[r] = 0.0;        // increment of the previous step (this lane's components)
+  }
 
   double* Yt = a.Y ? a.Y + (size_t)traj * a.n_t * NV : nullptr;
   double* St = a.S ? a.S + (size_t)traj * a.n_t * NV * NK : nullptr;
@@ -1640,11 +1607,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
   double t = a.opts.t0;
   bool failed = !(h0 > 0.0);
   if (failed) status = SBM_STEP_UNDERFLOW;
-
-  double m[M::IM_NM];
-#pragma unroll
-  for (int e = 0; e < M::IM_NM; ++e) m[e] = 0.0;
-  double dy_prev = 0.0, hs_prev = 0.0;   // increment of the previous step (this lane's component), its step size
+  double hs_prev = 0.0;      // step size of the previous step
 
   for (int io = 0; io < glen; ++io) {
     const double target = tg[io];
@@ -1658,7 +1621,9 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
         const double t0 = t;
         // Newton starts from the midpoint the previous step's increment predicts (free, and good for the
         // smooth solutions a fixed step resolves): 2.6 -> about 2 iterations per step on stiff50
-        dy_prev *= (hs_prev > 0.0) ? hs / hs_prev : 0.0;
+        const double hsc = (hs_prev > 0.0) ? hs / hs_prev : 0.0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) dy_prev[r] *= hsc;
         hs_prev = hs;
         for (int s = 0; s < ns && !failed; ++s) {
          // SBM_IMPLICIT_MIDPOINT_GRADED: the very first step of a trajectory is cut into GRADE + 1 midpoint
@@ -1682,75 +1647,19 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
           const double hh = 0.5 * hsub;
           const double tm = t_sub + hh;
           t_sub += hsub;
-          double yb = fma(0.5, dy_prev, y);
-          bool conv = false;
-          for (int it = 0; it < MAXIT && !conv; ++it) {
-            ++n_newton;
-            sh.Y[lane] = yb;
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            double ys[M::RL_MAXYS];
+          double yb[RPL];
 #pragma unroll
-            for (int q = 0; q < M::RL_MAXYS; ++q) ys[q] = sh.Y[yidx[q]];
-            double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
-#pragma unroll
-            for (int q = 0; q < M::RL_MAXJY; ++q) jy[q] = 0.0;
-#pragma unroll
-            for (int q = 0; q < M::RL_MAXJP; ++q) jp[q] = 0.0;
-            M::class_dispatch(cls, tm, ys, ps, f, jy, jp);
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-#pragma unroll
-            for (int q = 0; q < M::RL_MAXJP; ++q) sh.A[apos[q]] = jp[q];
-#pragma unroll
-            for (int q = 0; q < M::RL_MAXJY; ++q) sh.JY[jyout[q]] = jy[q];
-            sh.G[lane] = has_row ? (yb - y) - hh * f : 0.0;
-            if constexpr (M::IM_TRI) {
-              double jd = 0.0;
-#pragma unroll
-              for (int q = 0; q < M::RL_MAXJY; ++q) jd = sbm_sel(diagslot == q, jy[q], jd);
-              const double rd = sbm_rcp(fma(-hh, jd, 1.0));
-              sh.MF[rdpos] = rd;
-#pragma unroll
-              for (int q = 0; q < M::RL_MAXJY; ++q) sh.MF[mfpos[q]] = hh * jy[q] * rd;
-            }
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            double b[NV];
-            if constexpr (M::IM_TRI) {
-#pragma unroll
-              for (int i = 0; i < NV; ++i) b[i] = sh.G[i];
-              M::im_solve_tri(sh.MF, b);
-              __atomic_signal_fence(__ATOMIC_SEQ_CST);
-            } else {
-              M::im_build(hh, sh.JY, m);
-              M::im_factor(m);
-#pragma unroll
-              for (int i = 0; i < NV; ++i) b[i] = sh.G[i];
-              __atomic_signal_fence(__ATOMIC_SEQ_CST);
-              M::im_solve(m, b);
-            }
-            const double d = has_row ? sbm_pick_tree<NV>(b, lane) : 0.0;   // lane i keeps delta_i
-            yb -= d;
-            float r = has_row ? (float)(fabs(d) / fma(rtol, fabs(yb), atol)) : 0.f;
-            r = sbm_wave_max(sbm_nan_to_inf(r));
-            conv = r <= 1.0f;                       // wave-uniform
-            if (!(r < 3.0e38f)) { status = SBM_NON_FINITE; failed = true; break; }
-          }
-          if (!failed && !conv) { status = SBM_NEWTON_FAIL; failed = true; }
-          if (failed) break;
+          for (int r = 0; r < RPL; ++r) yb[r] = fma(0.5, dy_prev[r], y[r]);
+          const int rc = st.template newton<12>(tm, hh, y, yb, rtol, atol, n_newton);
+          if (rc != SBM_OK) { status = rc; failed = true; break; }
           // predictor for the next (sub)step: this increment, rescaled when the next substep is twice as long
-          dy_prev = 2.0 * (yb - y) * ((nsub > 1 && gj > 0 && sub % gm_ == gm_ - 1) ? 2.0 : 1.0);
-          y = fma(2.0, yb, -y);
-          if (with_sens) {
-            // J_y (the factors in m) and J_p (A) are those of the last evaluated iterate: within the
-            // Newton tolerance of the converged midpoint
-            double b[NV];
+          const double psc = (nsub > 1 && gj > 0 && sub % gm_ == gm_ - 1) ? 2.0 : 1.0;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) b[i] = fma(hh, sh.A[i * 64 + lane], z[i]);
-            if constexpr (M::IM_TRI) M::im_solve_tri(sh.MF, b);
-            else M::im_solve(m, b);
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) z[i] = fma(2.0, b[i], -z[i]);
+          for (int r = 0; r < RPL; ++r) {
+            dy_prev[r] = 2.0 * (yb[r] - y[r]) * psc;
+            y[r] = fma(2.0, yb[r], -y[r]);
           }
+          if (with_sens) st.sens(hh, z);
          }
           if (!failed) {
             // the graded block covered the first gm_ steps of this interval
@@ -1764,9 +1673,14 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
     if (failed) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) z[i] = __builtin_nan("");
-      y = __builtin_nan("");
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) y[r] = __builtin_nan("");
     }
-    if (Yt && has_row && chunk == 0) Yt[(size_t)io * NV + lane] = y;
+    if (Yt && chunk == 0) {
+#pragma unroll
+      for (int r = 0; r < RPL; ++r)
+        if (st.has_row[r]) Yt[(size_t)io * NV + lane + 64 * r] = y[r];
+    }
     if (St && has_col) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + col] = z[i];
@@ -1782,6 +1696,15 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
 #include "sbm_implicit_adaptive.hpp"
 #include "sbm_sens_mfma.hpp"
 
+// What the implicit kernels can hold: every lane keeps a whole column of S (NV values) and the solver's work vector
+// in registers (4 NV VGPRs: beyond about 110 state variables the compiler spills), the error-controlled kernel parks two
+// more copies of S in LDS.
+template <class M>
+struct SbmImplicitFits {
+  static constexpr bool fixed = M::NV <= SBM_IMPLICIT_MAX_NV && sizeof(SbmImidShared<M>) <= 160u * 1024u;
+  static constexpr bool adaptive = M::NV <= SBM_IMPLICIT_MAX_NV && sizeof(SbmImadShared<M>) <= 160u * 1024u;
+};
+
 // ---------------------------------------------------------------------------
 // host-side launcher used by sbm_plugin_main.hip
 // ---------------------------------------------------------------------------
@@ -1793,7 +1716,7 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
   const sbm_kernel_args a = *args;
   if (a.n_traj <= 0) return (int)hipSuccess;
   if (a.opts.method == SBM_IMPLICIT_ADAPTIVE) {
-    if constexpr (M::NV <= 64) {
+    if constexpr (SbmImplicitFits<M>::adaptive) {
       const int nch = a.S ? (M::NK + 63) / 64 : 1;
       if (nch > 1) {     // chunks combine status / counts with atomicMax
         hipError_t e = hipSuccess;
@@ -1810,13 +1733,13 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
   }
   if (a.opts.method == SBM_IMPLICIT_MIDPOINT || a.opts.method == SBM_IMPLICIT_MIDPOINT_GRADED) {
     // one trajectory per wave for both kinds (state only: S == NULL skips the column work)
-    if constexpr (M::NV <= 64) {
+    if constexpr (SbmImplicitFits<M>::fixed) {
       // state only: one wavefront; with sensitivities: one per chunk of 64 columns
       const int nch = a.S ? (M::NK + 63) / 64 : 1;
       hipLaunchKernelGGL((sbm_imid_kernel<M>), dim3(a.n_traj, nch), dim3(64), 0, stream, a);
       return (int)hipGetLastError();
     } else {
-      return (int)hipErrorInvalidConfiguration;   // needs one row per lane
+      return (int)hipErrorInvalidConfiguration;   // see SbmImplicitFits
     }
   }
   // J_y S on the matrix cores (sbm_sens_mfma.hpp) costs the same whatever the sparsity of J_y; the scalar kernels cost

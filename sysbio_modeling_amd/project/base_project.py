@@ -656,7 +656,7 @@ class Project(object):
             out, st, steps, stiff = _control.with_stiff_fallback(
                 lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=-budget,
                                                   rtol=rtol, atol=atol, extrapolate=0, **keep)),
-                implicit if self._model.n_vars <= 64 else None, V)
+                implicit if self._model.n_vars <= _lib.IMPLICIT_MAX_NV else None, V)
         out['status'] = torch.as_tensor(st, dtype=torch.int32, device=th.device)
         out['n_steps'] = torch.as_tensor(np.minimum(steps, 2 ** 31 - 1), dtype=torch.int32, device=th.device)
         out['stiff'] = torch.as_tensor(stiff, device=th.device)

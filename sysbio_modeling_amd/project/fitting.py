@@ -17,7 +17,7 @@ from .. import _lib
 
 
 def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambda_up=4.0, lambda_down=3.0,
-                              ftol=1.49012e-8, xtol=1.49012e-8, max_step=2.0, **integrator_overrides):
+                              ftol=1.49012e-8, xtol=1.49012e-8, max_step=2.0, trace=False, **integrator_overrides):
     """Minimise 0.5 |r(theta)|^2 from every row of ``thetas0`` (V, q), independently.
 
     Marquardt damping per start: a step is accepted when the cost decreases (lambda /= lambda_down),
@@ -36,7 +36,9 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     sensitivity kernel use its small-batch split while starts x experiments x chunks <= 1024.
 
     Returns a dict of numpy arrays: theta (V, q), cost (V,) = 0.5 |r|^2, n_iter (V,) iterations until
-    convergence (max_iter if never), converged (V,) bool, n_evaluations (total trial points integrated).
+    convergence (max_iter if never), converged (V,) bool, n_evaluations (total trial points integrated); with
+    ``trace=True`` also 'history': per iteration the number of accepted steps, starts still running, median cost,
+    damping, relative decrease and largest step component (costs a device synchronisation per iteration).
     """
     import torch
     integrator_overrides.setdefault('max_steps', -20000)     # negative: budget with early exit (include/sbm.h)
@@ -75,6 +77,7 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     done = ~torch.isfinite(cost)                      # a start that cannot be integrated stays where it is
     n_iter = torch.full((V,), int(max_iter), dtype=torch.int64, device=dev)
     n_eval = V
+    history = []
     p = _lib.dev_ptr
     for it in range(max_iter):
         # finite stand-ins where the current point is unusable (their steps are discarded below)
@@ -94,15 +97,23 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
         small_f = ok & free & ((cost - cost_t) <= ftol * cost) & (pred <= ftol * cost)
         # a negligible step ends the search whether or not it still lowers the cost (at the rounding floor it does not)
         small_x = (st == 0) & ~done & free & (delta.abs() <= xtol * (th.abs() + xtol)).all(dim=1)
+        cost_prev = cost
         th = torch.where(ok[:, None], trial, th)
         r = torch.where(ok[:, None], r_t, r)
         J = torch.where(ok[:, None, None], J_t, J)
         cost = torch.where(ok, cost_t, cost)
         lam = torch.where(ok, lam / lambda_down, lam * lambda_up).clamp(1e-15, 1e15)
         newly = (small_f | small_x) & ~done
+        if trace:
+            live = ~done
+            history.append(dict(iteration=it, accepted=int((ok & live).sum()), live=int(live.sum()),
+                                cost_median=float(cost.median()), lambda_median=float(lam[live].median()) if bool(live.any()) else 0.0,
+                                rel_decrease_median=float(((cost_prev - cost) / cost_prev)[live].median()) if bool(live.any()) else 0.0,
+                                step_max_median=float(delta.abs().max(dim=1).values[live].median()) if bool(live.any()) else 0.0))
         n_iter = torch.where(newly, torch.full_like(n_iter, it + 1), n_iter)
         done = done | newly
         if bool(done.all()):
             break
     return {'theta': th.cpu().numpy(), 'cost': cost.cpu().numpy(), 'n_iter': n_iter.cpu().numpy(),
-            'converged': (done & torch.isfinite(cost)).cpu().numpy(), 'n_evaluations': n_eval}
+            'converged': (done & torch.isfinite(cost)).cpu().numpy(), 'n_evaluations': n_eval,
+            **({'history': history} if trace else {})}

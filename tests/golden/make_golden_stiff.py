@@ -1,8 +1,10 @@
-"""Generate tests/golden/stiff50_ref.npz with the REAL reference OdeModel (BASELINE configs[4]).
+"""Generate tests/golden/stiff50_ref.npz (BASELINE configs[4]) and stiff80_ref.npz (the same cascade with 80 states:
+more state variables than a wavefront has lanes) with the REAL reference OdeModel.
 
 Run in the build container only (it reads /root/reference):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_stiff.py        (~2 minutes)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_stiff.py            (~2 minutes)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_stiff.py 80 2       (80 states, 2 vectors: ~40 minutes)
 
 The reference's ``OdeModel.simulate`` / ``calc_jacobian`` (model/ode_model.py:83-169: odeint -> LSODA,
 rtol = atol = 1e-10, Dfun=None) integrate the build's stiff50 model; the right-hand sides handed to it
@@ -39,13 +41,15 @@ def c_callable(cfn):
     return f
 
 
-def main():
-    gm = zoo_model('stiff50')
+def main(n_states=50, n_vectors=3):
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    name = 'stiff%d' % n_states
+    gm = zoo_model('stiff50') if n_states == 50 else GeneratedModel(models_zoo.stiff_spec(n_states, name=name))
     lib = gm.c_library()
     m = ref_ode_model.OdeModel(c_callable(lib.sbm_rhs), c_callable(lib.sbm_sens_rhs), gm.n_vars,
                                list(gm.param_order), use_jit=False)
-    _, P = models_zoo.stiff_ensemble(4096)
-    P = P[:3]
+    _, P = models_zoo.stiff_ensemble(4096, n=n_states)
+    P = P[:n_vectors]
     grid = np.linspace(0, models_zoo.STIFF_T_END, 1000)
     idx = np.searchsorted(grid, models_zoo.STIFF_MEASURE_TIMES)
     n, k = gm.n_vars, gm.n_sens
@@ -53,9 +57,9 @@ def main():
     for p in P:
         Ys.append(m.simulate(p, grid)[idx])
         Ss.append(m.calc_jacobian(p, grid, np.zeros(n + n * k))[idx])
-        print('stiff50 vector done', flush=True)
-    np.savez_compressed(os.path.join(HERE, 'stiff50_ref.npz'), P=P, t=grid, idx=idx, Y=np.stack(Ys), S=np.stack(Ss))
+        print(name, 'vector done', flush=True)
+    np.savez_compressed(os.path.join(HERE, name + '_ref.npz'), P=P, t=grid, idx=idx, Y=np.stack(Ys), S=np.stack(Ss))
 
 
 if __name__ == '__main__':
-    main()
+    main(*[int(x) for x in sys.argv[1:3]])

@@ -402,3 +402,87 @@ def test_single_vector_methods_integrate_a_stiff_vector_under_default_options(gp
     y2 = m.simulate(mild, t_out)
     assert m.last_info['stiff'].tolist() == [False]
     assert np.array_equal(y2, m.simulate_batch(mild[None, :], t_out)[0])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# more state variables than a wavefront has lanes: state component i lives on lane i mod 64 (sbm_implicit_stepper.hpp)
+# ----------------------------------------------------------------------------------------------------------------
+_big = {}
+
+
+def _big_model(kind, n):
+    """(GeneratedModel, OdeModel) of an n-state stiff cascade ('stiff') or activation cascade ('cascade')"""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.model import OdeModel
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    if (kind, n) not in _big:
+        spec = (models_zoo.stiff_spec(n, name='stiff%d' % n) if kind == 'stiff'
+                else models_zoo.cascade_spec(n, name='cascade%d' % n))
+        gm = GeneratedModel(spec)
+        _big[(kind, n)] = (gm, OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=spec.name))
+    return _big[(kind, n)]
+
+
+def test_eighty_state_stiff_cascade_equals_the_scheme_oracle():
+    """stiff80 (80 states, 80 sensitivity columns: 6480 coupled ODEs, two rows per lane and two column chunks) through
+    the fixed-step kernel against the dense numpy restatement of the scheme (oracle/imid_oracle.py)."""
+    from oracle import imid_oracle
+    from sysbio_modeling_amd import models_zoo
+    gm, m = _big_model('stiff', 80)
+    P = models_zoo.stiff_ensemble(2, n=80)[1]
+    t_out = np.array([0.0, 3.7, 10.0])
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, h0=0.02, **IM)
+    assert m.last_info['status'].tolist() == [0, 0]
+    for v in range(2):
+        Yo, So, ns, nn = imid_oracle.integrate(gm, P[v], t_out[1:], 0.02)
+        assert m.last_info['n_steps'][v] == ns
+        assert np.allclose(Y[v, 1:], Yo, rtol=1e-9, atol=1e-12)
+        assert np.allclose(S[v, 1:], So, rtol=1e-8, atol=1e-10 * np.abs(So).max())
+    assert np.array_equal(m.simulate_batch(P, t_out, h0=0.02, **IM), Y)
+    # feed-forward structure survives the two-rows-per-lane bookkeeping: d x_i / d a_j = 0 for j > i
+    S4 = S.reshape(2, 3, 80, 80)
+    up = np.triu_indices(80, k=1)
+    assert np.all(S4[:, :, up[0], up[1]] == 0.0) and np.abs(S4[:, -1, np.arange(80), np.arange(80)]).min() > 0.0
+
+
+def test_eighty_state_stiff_cascade_against_reference_golden(golden):
+    """tests/golden/stiff80_ref.npz: the REAL reference OdeModel (LSODA on its BDF branch) on stiff80, 2 vectors
+    (make_golden_stiff.py 80 2).  The in-kernel controlled integrator with default options, the fixed-step Richardson
+    pair, and method='auto' (DOPRI45 gives up, the implicit kernel takes over) all meet the parity tolerance."""
+    g = golden('stiff80_ref.npz')
+    gm, m = _big_model('stiff', 80)
+    P = g['P']
+    t_out = _from_zero(g['t'][g['idx']])
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled')
+    info = m.last_info
+    assert not info['status'].any()
+    ey, es = parity_err(Y[:, 1:], g['Y']), parity_err(S[:, 1:], g['S'])
+    print("implicit_controlled on stiff80: %s coarse steps (+%s abandoned); error vs LSODA golden y %.2f S %.2f units"
+          % (info['n_steps'], info['n_rejected'], ey, es))
+    Sf, Yf = m.calc_jacobian_batch(P, t_out, return_states=True, n_steps=4096, extrapolate=1, **IM)
+    assert not m.last_info['status'].any()
+    eyf, esf = parity_err(Yf[:, 1:], g['Y']), parity_err(Sf[:, 1:], g['S'])
+    print("fixed 4096 + 8192 Richardson on stiff80: y %.2f S %.2f units" % (eyf, esf))
+    assert eyf <= 1.0 and esf <= 1.0
+    # LSODA's own error on this family is about one unit (stiff50: tests/golden/stiff50_tight.npz); the two GPU
+    # integrators, which share nothing but the midpoint rule's step, agree with each other more closely than that
+    assert ey <= 1.0 and es <= max(1.0, 1.05 * esf) and parity_err(S[:, 1:], Sf[:, 1:]) <= 1.0
+    Sa = m.calc_jacobian_batch(P[:1], t_out, method='auto', max_steps=20000)
+    assert m.last_info['stiff'].tolist() == [True] and parity_err(Sa[:, 1:], g['S'][:1]) <= max(1.0, 1.05 * esf)
+
+
+def test_controlled_implicit_kernel_on_a_seventy_state_model_agrees_with_dopri45():
+    """cascade70 (not stiff): the error-controlled implicit kernel and DOPRI45 at their default options solve the same
+    problem -- state and all 70 x 140 sensitivities -- to the parity tolerance."""
+    from sysbio_modeling_amd import models_zoo
+    gm, m = _big_model('cascade', 70)
+    rng = np.random.default_rng(70)
+    P = models_zoo.cascade_nominal_params(70)[None, :] * np.exp(0.2 * rng.standard_normal((2, 140)))
+    t_out = np.array([0.0, 10.0, 30.0, 60.0])
+    Se, Ye = m.calc_jacobian_batch(P, t_out, return_states=True)
+    assert not m.last_info['status'].any()
+    Si, Yi = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled')
+    assert not m.last_info['status'].any()
+    ey, es = parity_err(Yi[:, 1:], Ye[:, 1:]), parity_err(Si[:, 1:], Se[:, 1:])
+    print("cascade70 implicit_controlled vs dopri45: y %.3f S %.3f units, %s coarse steps" % (ey, es, m.last_info['n_steps']))
+    assert ey <= 1.0 and es <= 1.0
