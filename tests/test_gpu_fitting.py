@@ -142,3 +142,30 @@ def test_multi_chain_sampler_reproduces_the_gaussian_posterior(gpu_models):
     # skip_elems thins the record, not the walk
     ens2, _, _ = ensemble_log_params_batch(proj, truth, steps=50, seeds=3, skip_elems=4)
     assert ens2.shape == (11, 1, 2)
+
+
+def test_sampler_with_recalculated_hessian(gpu_models):
+    """ensemble_log_params_batch(recalc_hess_alg=True): the reference's second algorithm (Ensembles.py:153-157, :200-224),
+    J^T J at every trial point from the batched device Jacobian and the Metropolis-Hastings ratio with both candidate
+    densities.  On the one-species model with noise-free data the posterior is N(theta*, (J^T J)^-1) to a good
+    approximation: pooled chains reproduce its standard deviations."""
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.project import Project
+    from sysbio_modeling_amd.project.ensembles import ensemble_log_params_batch
+    m = gpu_models('simple')
+    t = np.linspace(5.0, 100.0, 20)
+    grid = np.linspace(0, 100.0, 1000)
+    y = m.simulate(np.array([0.05, 0.3]), np.concatenate([[0.0], grid[np.searchsorted(grid, t)]]))[1:, 0]
+    exp = Experiment('E', TimecourseMeasurement('Variable_1', y, t, 0.01 * y))
+    proj = Project(m, [exp], {'Global': ['k_deg', 'k_synt']}, {'Variable_1': ('direct', 0)}, reference_compat=False)
+    truth = np.zeros(2)
+    truth[proj.get_param_index('k_deg', 'Global')] = np.log(0.05)
+    truth[proj.get_param_index('k_synt', 'Global')] = np.log(0.3)
+    J = proj.calc_project_jacobian(truth)
+    sd = np.sqrt(np.diag(np.linalg.inv(J.T @ J)))
+    ens, ens_F, ratio = ensemble_log_params_batch(proj, np.tile(truth, (128, 1)), steps=250, seeds=3, recalc_hess_alg=True)
+    assert ens.shape == (251, 128, 2) and 0.3 < ratio.mean() < 0.8 and np.all(ens_F >= 0)
+    pooled = ens[60:].reshape(-1, 2)
+    assert np.all(np.abs(pooled.mean(axis=0) - truth) < 0.12 * sd)
+    assert np.allclose(pooled.std(axis=0), sd, rtol=0.15)
