@@ -56,7 +56,9 @@ struct SbmImadShared {
   double Y[NROW];               // iterate, one component per row lane (rows lane, lane + 64, ...)
   double G[NROW];               // Newton residual
   double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
-  double MF[M::IM_NM + 2];      // IM_TRI: reciprocal pivots and scaled entries, written row by row lane
+  static constexpr int MF_SIZE = sbm_imf_size<M>(), RD_SIZE = sbm_ird_size<M>();
+  __attribute__((aligned(16))) double MF[MF_SIZE];   // the factors (IM_TRI: reciprocal pivots and scaled entries; IM_DIST: dense rows)
+  double RD[RD_SIZE];           // IM_DIST: reciprocal pivots
   double A[A_SIZE];             // J_p: [row][slot] or [row][column]
   static constexpr int ZC = M::NK < 64 ? M::NK : 64;     // columns of a chunk that exist
   static constexpr int ZS = ZC < 64 ? ZC + 1 : 64;       // + one spare column that the idle lanes share (all zeros)

@@ -16,8 +16,16 @@
 // and read from the table MF) to its own right-hand side: the Newton residual (picked apart again: the lane of row i
 // keeps delta_i) and its sensitivity column.
 //
-// The shared-memory struct Sh provides: Y[NROW], G[NROW] (NROW = 64 RPL), JY[NJY + 2], MF[IM_NM + 2], A[A_SIZE] and
-// the constants A_SPARSE (J_p stored [row][slot] instead of [row][64 columns]) and A_SIZE (last slot = spare).
+// Three forms of the factorisation, chosen by the model's pattern (emit_implicit.py):
+//   IM_TRI   lower triangular: no elimination; row lane i publishes 1 / M_ii and its scaled row in MF;
+//   IM_DIST  anything else on up to 64 state variables: lane i holds row i of M as a dense register row, the lanes
+//            eliminate together (pivot rows travel by v_readlane), the finished rows are published in MF
+//            ([row][IM_LD]) with the reciprocal pivots in RD; the substitutions read both with wave-uniform addresses;
+//   neither  (more than 64 state variables, not triangular): every lane factors the whole matrix in its own registers.
+//
+// The shared-memory struct Sh provides: Y[NROW], G[NROW] (NROW = 64 RPL), JY[NJY + 2], MF[MF_SIZE], RD[RD_SIZE],
+// A[A_SIZE] and the constants A_SPARSE (J_p stored [row][slot] instead of [row][64 columns]), A_SIZE (last slot =
+// spare), MF_SIZE = sbm_imf_size<M>() (last slot = spare) and RD_SIZE = sbm_ird_size<M>().
 #pragma once
 
 #include <type_traits>
@@ -47,6 +55,12 @@ __device__ __forceinline__ double sbm_pick_slice(const double (&v)[N], int lane)
   }
 }
 
+// sizes of the factor tables in LDS
+template <class M>
+constexpr int sbm_imf_size() { return (M::IM_DIST ? M::NV * M::IM_LD : M::IM_NM) + 2; }
+template <class M>
+constexpr int sbm_ird_size() { return M::IM_DIST ? M::NV : 1; }
+
 template <class M, class Sh>
 struct SbmImplicitStepper {
   static constexpr int NV = M::NV;
@@ -60,7 +74,13 @@ struct SbmImplicitStepper {
   int yidx[RPL][M::RL_MAXYS], jyout[RPL][M::RL_MAXJY], apos[RPL][M::RL_MAXJP], mfpos[RPL][M::RL_MAXJY];
   int rdpos[RPL], diagslot[RPL];
   double ps[RPL][M::RL_MAXPS];
-  double m[M::IM_NM];
+#ifdef SBM_IMPLICIT_REDUNDANT_LU                   // developer A/B switch: the redundant form where the distributed one applies
+  static constexpr bool DIST = false;
+#else
+  static constexpr bool DIST = M::IM_DIST;         // (RPL == 1 there)
+#endif
+  static constexpr int MFSPARE = Sh::MF_SIZE - 1;
+  double m[(DIST || M::IM_TRI) ? 1 : M::IM_NM];    // the redundant form's factors
 
   __device__ __forceinline__ static void fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 
@@ -73,7 +93,8 @@ struct SbmImplicitStepper {
     constexpr int NCH = (M::NK + 63) / 64;
     for (int i = lane; i < Sh::A_SIZE; i += 64) sh->A[i] = 0.0;
     for (int i = lane; i < M::NJY + 2; i += 64) sh->JY[i] = 0.0;
-    for (int i = lane; i < M::IM_NM + 2; i += 64) sh->MF[i] = 0.0;
+    for (int i = lane; i < Sh::MF_SIZE; i += 64) sh->MF[i] = 0.0;
+    for (int i = lane; i < Sh::RD_SIZE; i += 64) sh->RD[i] = 1.0;
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
       sh->Y[lane + 64 * r] = 0.0;
@@ -99,13 +120,57 @@ struct SbmImplicitStepper {
           apos[r][s] = (hr && lc >= 0 && lc < 64) ? row * 64 + lc : ASPARE;
         }
       }
+      if constexpr (DIST) {
+        // where slot s of this lane's row goes in the dense table, and which slot (if any) is the diagonal entry
+        diagslot[r] = -1;
 #pragma unroll
-      for (int s = 0; s < M::RL_MAXJY; ++s) mfpos[r][s] = (M::IM_TRI && hr) ? M::im_mfpos(s, row) : M::IM_NM + 1;
-      rdpos[r] = (M::IM_TRI && hr) ? M::im_rstart(row) : M::IM_NM + 1;
-      diagslot[r] = (M::IM_TRI && hr) ? M::im_diagslot(row) : -1;
+        for (int s = 0; s < M::RL_MAXJY; ++s) {
+          const int c = M::rl_jycol(s, row);
+          mfpos[r][s] = (hr && c >= 0) ? row * M::IM_LD + c : MFSPARE;
+          if (hr && c == row) diagslot[r] = s;
+        }
+        rdpos[r] = hr ? row * M::IM_LD : MFSPARE;       // start of this lane's row
+      } else {
+#pragma unroll
+        for (int s = 0; s < M::RL_MAXJY; ++s) mfpos[r][s] = (M::IM_TRI && hr) ? M::im_mfpos(s, row) : MFSPARE;
+        rdpos[r] = (M::IM_TRI && hr) ? M::im_rstart(row) : MFSPARE;
+        diagslot[r] = (M::IM_TRI && hr) ? M::im_diagslot(row) : -1;
+      }
     }
 #pragma unroll
-    for (int e = 0; e < M::IM_NM; ++e) m[e] = 0.0;
+    for (int e = 0; e < (int)(sizeof(m) / sizeof(double)); ++e) m[e] = 0.0;
+  }
+
+  // IM_DIST: build this lane's row of M = I - hh J_y in the LDS table, read it back as a dense register row, factor
+  // with the other lanes, publish.  jy: the class outputs of this lane's row.
+  __device__ __forceinline__ void factor_rows(double hh, const double (&jy)[M::RL_MAXJY]) {
+    static_assert(!DIST || RPL == 1, "distributed factorisation: one row per lane");
+    constexpr int LD = M::IM_LD;
+    double* myrow = sh->MF + (has_row[0] ? rdpos[0] : 0);
+    if (has_row[0]) {
+      // the table still holds the previous factors: clear the row (16-byte stores), then scatter the entries of M
+#pragma unroll
+      for (int j = 0; j + 1 < LD; j += 2) *reinterpret_cast<double2*>(myrow + j) = double2{0.0, 0.0};
+      fence();
+      myrow[lane] = 1.0;
+    }
+    fence();
+#pragma unroll
+    for (int q = 0; q < M::RL_MAXJY; ++q) {
+      const double v = -hh * jy[q];
+      sh->MF[mfpos[0][q]] = diagslot[0] == q ? 1.0 + v : v;
+    }
+    fence();
+    double row[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) row[j] = myrow[j];
+    fence();
+    M::im_factor_rows(row, lane, sh->RD);
+    if (has_row[0]) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) myrow[j] = row[j];
+    }
+    fence();
   }
 
   // Newton on the midpoint state of one step of size 2*hh from y: on entry yb = predictor, on exit the midpoint.
@@ -133,8 +198,10 @@ struct SbmImplicitStepper {
         fence();
 #pragma unroll
         for (int q = 0; q < M::RL_MAXJP; ++q) sh->A[apos[r][q]] = jp[q];
+        if constexpr (!M::IM_TRI && !DIST) {      // (only the redundant form reads the entry list)
 #pragma unroll
-        for (int q = 0; q < M::RL_MAXJY; ++q) sh->JY[jyout[r][q]] = jy[q];
+          for (int q = 0; q < M::RL_MAXJY; ++q) sh->JY[jyout[r][q]] = jy[q];
+        }
         sh->G[lane + 64 * r] = has_row[r] ? (yb[r] - y[r]) - hh * f : 0.0;
         if constexpr (M::IM_TRI) {
           double jd = 0.0;
@@ -144,11 +211,18 @@ struct SbmImplicitStepper {
           sh->MF[rdpos[r]] = rd;
 #pragma unroll
           for (int q = 0; q < M::RL_MAXJY; ++q) sh->MF[mfpos[r][q]] = hh * jy[q] * rd;
+        } else if constexpr (DIST) {
+          factor_rows(hh, jy);
         }
       }
       fence();
       double b[NV];
-      if constexpr (M::IM_TRI) {
+      if constexpr (DIST) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
+        M::im_solve_lds(sh->MF, sh->RD, b);
+        fence();
+      } else if constexpr (M::IM_TRI) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
         M::im_solve_tri(sh->MF, b);
@@ -194,7 +268,8 @@ struct SbmImplicitStepper {
     double b[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) b[i] = fma(hh, a_of(i), z[i]);
-    if constexpr (M::IM_TRI) M::im_solve_tri(sh->MF, b);
+    if constexpr (DIST) M::im_solve_lds(sh->MF, sh->RD, b);
+    else if constexpr (M::IM_TRI) M::im_solve_tri(sh->MF, b);
     else M::im_solve(m, b);
     fence();
 #pragma unroll

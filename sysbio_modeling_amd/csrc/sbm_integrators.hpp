@@ -1562,7 +1562,9 @@ struct SbmImidShared {
   double G[NROW];               // Newton residual
   double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
   double A[A_SIZE];             // A[i][c] = J_p[i][c] (+ spare slot)
-  double MF[M::IM_NM + 2];      // IM_TRI: reciprocal pivots and scaled entries, written row by row lane
+  static constexpr int MF_SIZE = sbm_imf_size<M>(), RD_SIZE = sbm_ird_size<M>();
+  __attribute__((aligned(16))) double MF[MF_SIZE];   // the factors (IM_TRI: reciprocal pivots and scaled entries; IM_DIST: dense rows)
+  double RD[RD_SIZE];           // IM_DIST: reciprocal pivots
 };
 
 template <class M>

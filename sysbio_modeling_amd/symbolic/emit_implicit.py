@@ -15,6 +15,15 @@ For a cascade (J_y lower bidiagonal) this is 2n-1 entries, no fill and no backwa
 n x n solve would be n^3/3 flops per factorisation.  Every lane of a wavefront runs the same code
 on the same (wave-uniform) matrix and its own right-hand side (one sensitivity column each).
 
+General patterns on up to 64 state variables get a form DISTRIBUTED OVER ROWS (IM_DIST): the redundant form above costs
+every lane the whole elimination (n^3/3 multiply-adds for a dense pattern) and keeps all IM_NM factors in registers of
+every lane (twice IM_NM VGPRs: a dense 20-state model would need 800).  In the distributed form lane i holds row i of
+M as a dense register row; at pivot k the lanes below scale their entry and subtract the pivot row, which reaches them
+as scalar operands through ``v_readlane`` (static lane, static register) -- per lane one multiply-add per entry of U
+instead of one per elimination update (dense: n^2/2 instead of n^3/3).  The finished rows and the reciprocal pivots are
+published in LDS (``im_factor_rows``) and the substitutions read them back with wave-uniform addresses
+(``im_solve_lds``), as the triangular form does.
+
 Lower-triangular patterns (feed-forward networks) need no elimination at all: the pivots are the
 diagonal entries.  For them the emitter adds a DISTRIBUTED form (IM_TRI): row lane i, which has just
 evaluated row i of J_y, computes its own reciprocal pivot and scaled off-diagonal entries -- one
@@ -46,6 +55,73 @@ def symbolic_lu(n, entries):
         ops.append((k, step))
     pattern = sorted((i, j) for i in range(n) for j in rows[i])
     return pattern, ops
+
+
+def lds_leading_dimension(n):
+    """Row stride (in doubles) of the n x n factor table in LDS: >= n and = 2 mod 32, so that the 64 lanes' 16-byte
+    reads of their own rows (stride 2 * LD dwords) fall on different banks."""
+    if n <= 2:
+        return 2
+    ld = ((n - 2 + 31) // 32) * 32 + 2
+    return ld
+
+
+def emit_distributed(spec, d, pattern, ops):
+    """IM_DIST members (see the module docstring).  ``pattern`` / ``ops``: symbolic_lu's."""
+    n = spec.n_vars
+    ld = lds_leading_dimension(n)
+    lower_only = all(j <= i for i, j in pattern)
+    # When it pays (measured, 1024 vectors x 512 fixed steps with sensitivities, scripts/dev_implicit_lu.py): the dense
+    # 20-state network (400 non-zeros, 2 470 elimination updates) 256 ms redundant -> 47 ms distributed, half density
+    # 148 -> 38 ms; cascade20 (bidiagonal + feedback corner: 37 updates) 3.9 -> 5.3 ms -- the distributed form
+    # handles dense rows whatever the pattern.  Chosen when the redundant elimination is long or its factors would
+    # not fit the register file.
+    n_updates = sum(len(upper) for _, step in ops for _, upper in step)
+    dist = (not lower_only) and n <= 64 and (n_updates > 8 * n or len(pattern) > 128)
+    L = ["  // ---- the same factorisation distributed over rows: lane i factors row i (emit_implicit.py); %d elimination"
+         % n_updates,
+         "  //      updates in the redundant form ----",
+         "  static constexpr bool IM_DIST = %s;" % ("true" if dist else "false"),
+         "  static constexpr int IM_LD = %d;     // row stride of the factor table in LDS" % ld]
+    if not dist:
+        L += ["  __device__ __forceinline__ static void im_factor_rows(double (&)[NV], int, double*) {}",
+              "  __device__ __forceinline__ static void im_solve_lds(const double*, const double*, double (&)[NV]) {}"]
+        return L
+    rows = [[j for (i, j) in pattern if i == r] for r in range(n)]
+    L += ["  // m: this lane's row of M = I - gamma J_y (dense, zeros outside the pattern).  On exit: multipliers left of",
+          "  // the diagonal, U from the diagonal on; rd[k] = 1 / pivot k (LDS, every lane writes the same value).",
+          "  __device__ __forceinline__ static void im_factor_rows(double (&m)[NV], int lane, double* rd) {"]
+    for k, step in ops:
+        upper = sorted(j for j in rows[k] if j > k)
+        L.append("    { const double rp = SBM_LANE_BCAST(SBM_RCP(m[%d]), %d); rd[%d] = rp;" % (k, k, k))
+        if step:
+            L.append("      const double l = lane > %d ? m[%d] * rp : 0.0; m[%d] = lane > %d ? l : m[%d];" % (k, k, k, k, k))
+            for j in upper:
+                L.append("      m[%d] = fma(-l, SBM_LANE_BCAST(m[%d], %d), m[%d]);" % (j, j, k, j))
+        L.append("    }")
+    L += ["  }",
+          "  // b <- M^-1 b with the rows im_factor_rows produced, published at mf[row * IM_LD + column]",
+          "  __device__ __forceinline__ static void im_solve_lds(const double* mf, const double* rd, double (&b)[NV]) {"]
+    cnt = 0
+    for i in range(n):
+        for c in rows[i]:
+            if c < i:
+                L.append("    b[%d] = fma(-mf[%d], b[%d], b[%d]);" % (i, i * ld + c, c, i))
+                cnt += 1
+        if cnt >= 24:
+            L.append("    SBM_LDS_FENCE();")
+            cnt = 0
+    for i in range(n - 1, -1, -1):
+        for c in rows[i]:
+            if c > i:
+                L.append("    b[%d] = fma(-mf[%d], b[%d], b[%d]);" % (i, i * ld + c, c, i))
+                cnt += 1
+        L.append("    b[%d] *= rd[%d];" % (i, i))
+        if cnt >= 24:
+            L.append("    SBM_LDS_FENCE();")
+            cnt = 0
+    L += ["  }"]
+    return L
 
 
 def emit_members(spec, d):
@@ -115,8 +191,10 @@ def emit_members(spec, d):
                 # keep the compiler from hoisting every table load to the top (2*IM_NM live registers)
                 L.append("    SBM_LDS_FENCE();")
         L += ["  }"]
+        L += emit_distributed(spec, d, pattern, ops)
         return L, dict(tri=True, rstart=rstart, pos=pos, nm=nm)
     L += ["  __device__ __forceinline__ static void im_solve_tri(const double*, double (&)[NV]) {}"]
+    L += emit_distributed(spec, d, pattern, ops)
     return L, dict(tri=False, nm=nm)
 
 

@@ -447,28 +447,29 @@ def test_eighty_state_stiff_cascade_equals_the_scheme_oracle():
 
 def test_eighty_state_stiff_cascade_against_reference_golden(golden):
     """tests/golden/stiff80_ref.npz: the REAL reference OdeModel (LSODA on its BDF branch) on stiff80, 2 vectors
-    (make_golden_stiff.py 80 2).  The in-kernel controlled integrator with default options, the fixed-step Richardson
-    pair, and method='auto' (DOPRI45 gives up, the implicit kernel takes over) all meet the parity tolerance."""
-    g = golden('stiff80_ref.npz')
+    (make_golden_stiff.py 80 2); stiff80_tight.npz: the oracle's LSODA call at rtol 1e-12 (make_golden_stiff_tight.py
+    80), which arbitrates where LSODA at the reference's 1e-10 is itself about one tolerance unit off (it is, as on
+    stiff50).  The in-kernel controlled integrator with default options, a fixed-step Richardson pair, and method='auto'
+    (DOPRI45 gives up, the implicit kernel takes over) all meet the parity tolerance."""
+    g, gt = golden('stiff80_ref.npz'), golden('stiff80_tight.npz')
     gm, m = _big_model('stiff', 80)
     P = g['P']
     t_out = _from_zero(g['t'][g['idx']])
     S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled')
     info = m.last_info
     assert not info['status'].any()
-    ey, es = parity_err(Y[:, 1:], g['Y']), parity_err(S[:, 1:], g['S'])
-    print("implicit_controlled on stiff80: %s coarse steps (+%s abandoned); error vs LSODA golden y %.2f S %.2f units"
-          % (info['n_steps'], info['n_rejected'], ey, es))
-    Sf, Yf = m.calc_jacobian_batch(P, t_out, return_states=True, n_steps=4096, extrapolate=1, **IM)
+    ey = check_parity(Y[:, 1:], g['Y'], gt['Y'], what='stiff80 states', criterion='parity')
+    es = check_parity(S[:, 1:], g['S'], gt['S'], what='stiff80 sensitivities', criterion='parity')
+    print("implicit_controlled on stiff80: %s coarse steps (+%s abandoned); error vs LSODA golden y %.2f S %.2f units,"
+          % (info['n_steps'], info['n_rejected'], ey[0], es[0]), "vs tight:", ey[1], es[1])
+    Sf, Yf = m.calc_jacobian_batch(P, t_out, return_states=True, n_steps=8192, extrapolate=1, **IM)
     assert not m.last_info['status'].any()
-    eyf, esf = parity_err(Yf[:, 1:], g['Y']), parity_err(Sf[:, 1:], g['S'])
-    print("fixed 4096 + 8192 Richardson on stiff80: y %.2f S %.2f units" % (eyf, esf))
-    assert eyf <= 1.0 and esf <= 1.0
-    # LSODA's own error on this family is about one unit (stiff50: tests/golden/stiff50_tight.npz); the two GPU
-    # integrators, which share nothing but the midpoint rule's step, agree with each other more closely than that
-    assert ey <= 1.0 and es <= max(1.0, 1.05 * esf) and parity_err(S[:, 1:], Sf[:, 1:]) <= 1.0
+    eyf = check_parity(Yf[:, 1:], g['Y'], gt['Y'], what='stiff80 states, fixed pair', criterion='parity')
+    esf = check_parity(Sf[:, 1:], g['S'], gt['S'], what='stiff80 sensitivities, fixed pair', criterion='parity')
+    print("fixed 8192 + 16384 Richardson on stiff80: vs golden y %.2f S %.2f units," % (eyf[0], esf[0]), "vs tight:", eyf[1], esf[1])
     Sa = m.calc_jacobian_batch(P[:1], t_out, method='auto', max_steps=20000)
-    assert m.last_info['stiff'].tolist() == [True] and parity_err(Sa[:, 1:], g['S'][:1]) <= max(1.0, 1.05 * esf)
+    assert m.last_info['stiff'].tolist() == [True]
+    check_parity(Sa[:, 1:], g['S'][:1], gt['S'][:1], what='stiff80 through method=auto', criterion='parity')
 
 
 def test_controlled_implicit_kernel_on_a_seventy_state_model_agrees_with_dopri45():
@@ -486,3 +487,55 @@ def test_controlled_implicit_kernel_on_a_seventy_state_model_agrees_with_dopri45
     ey, es = parity_err(Yi[:, 1:], Ye[:, 1:]), parity_err(Si[:, 1:], Se[:, 1:])
     print("cascade70 implicit_controlled vs dopri45: y %.3f S %.3f units, %s coarse steps" % (ey, es, m.last_info['n_steps']))
     assert ey <= 1.0 and es <= 1.0
+
+
+def test_dense_coupled_stiff_network_row_distributed_lu():
+    """dense20 (every species coupled to every other: J_y full, 400 non-zeros) with degradation rates spread over four
+    decades: a stiff problem whose Newton matrix is dense.  The factorisation runs distributed over the row lanes
+    (emit_implicit.py IM_DIST, sbm_implicit_stepper.hpp::factor_rows).  Scheme level: the fixed-step kernel equals the
+    dense numpy restatement; reference level: the error-controlled kernel meets the parity tolerance against the
+    oracle's LSODA call."""
+    from oracle import imid_oracle
+    from oracle import odeint_oracle as oo
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.model import OdeModel
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    gm = GeneratedModel(models_zoo.dense_spec(density=1.0))
+    assert 'IM_DIST = true' in gm.hip_source
+    gm.c_library()
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=gm.spec.name)
+    rng = np.random.default_rng(12)
+    d = 10.0 ** np.linspace(0.0, 4.0, 20)
+    P = np.stack([np.concatenate([d * rng.uniform(0.5, 2.0, 20), d * rng.uniform(0.8, 1.25, 20)]) for _ in range(2)])
+    t_out = np.array([0.0, 0.4, 2.0])
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, h0=0.002, **IM)
+    assert m.last_info['status'].tolist() == [0, 0]
+    for v in range(2):
+        Yo, So, ns, nn = imid_oracle.integrate(gm, P[v], t_out[1:], 0.002)
+        assert m.last_info['n_steps'][v] == ns
+        assert np.allclose(Y[v, 1:], Yo, rtol=1e-9, atol=1e-12)
+        assert np.allclose(S[v, 1:], So, rtol=1e-8, atol=1e-10 * np.abs(So).max())
+    # a step five times longer starts too far from the fast species' initial layer for Newton on the second vector: the
+    # restatement gives up there too (same predictor, same iteration limit), and the kernel says which vector it was
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m.simulate_batch(P, t_out, h0=0.01, **IM)
+    assert m.last_info['status'].tolist() == [0, 4]
+    with pytest.raises(RuntimeError):
+        imid_oracle.integrate(gm, P[1], t_out[1:], 0.01)
+    grid = np.linspace(0.0, 2.0, 1000)
+    idx = np.array([200, 999])
+    t2 = _from_zero(grid[idx])
+    Sc, Yc = m.calc_jacobian_batch(P, t2, return_states=True, method='implicit_controlled')
+    assert m.last_info['status'].tolist() == [0, 0]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m.simulate_batch(P, t2, method='dopri45', max_steps=-20000)
+    explicit_status = m.last_info['status'].tolist()
+    for v in range(2):
+        Sr, Yr = oo.calc_jacobian(gm, P[v], grid, use_c=True, return_states=True)
+        tight = oo.tight_solution(gm, P[v], t2, use_c=True)[1:]
+        check_parity(np.concatenate([Yc[v, 1:], Sc[v, 1:]], axis=1), np.concatenate([Yr[idx], Sr[idx]], axis=1), tight,
+                     what='dense20 stiff vector %d' % v, criterion='parity')
+    print("dense20 stiff: implicit_controlled %s coarse steps; DOPRI45 with a 20000-step budget: status %s"
+          % (m.last_info['n_steps'], explicit_status))
