@@ -74,7 +74,8 @@ typedef struct sbm_integrator_opts {
   int32_t max_steps; /* per trajectory, accepted + rejected; 0 -> 1000000.  DOPRI45, negative: a budget of
                       * |max_steps| with an early exit (status SBM_MAX_STEPS at once) for a trajectory whose
                       * current step size would need more than four budgets for the remaining time span --
-                      * checked every 256 attempts from the 512th on: the explicit method on a stiff system */
+                      * checked every 256 attempts from the 512th on, and only while the step size has stopped
+                      * growing from one check to the next: the explicit method on a stiff system */
   double rtol;       /* DOPRI45, IMPLICIT_ADAPTIVE: relative tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
   double atol;       /* DOPRI45, IMPLICIT_ADAPTIVE: absolute tolerance; IMPLICIT_MIDPOINT: Newton tolerance */
   double h0;         /* RK4, IMPLICIT_MIDPOINT: step size; DOPRI45: initial step (<=0 -> automatic) */

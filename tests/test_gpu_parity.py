@@ -813,3 +813,34 @@ def test_large_batch_indexing(gpu_models):
     assert np.array_equal(Y[pick].cpu().numpy(), Y_small)
     del S, Y
     torch.cuda.empty_cache()
+
+
+def test_step_budget_with_early_exit_stays_quiet_on_slow_starting_runs(gpu_models):
+    """The default options carry a step budget with an early exit (max_steps = -50000: a trajectory whose current step
+    size could not finish within four budgets gives up at once -- an explicit method on a stiff system).  A run that is
+    NOT stiff but starts with small steps on a long horizon must not be mistaken for one: the cascade's transient (t < 100)
+    takes ~1000 steps of 0.1, at which rate a horizon of 3 10^4 or 10^5 looks like 3 10^5 / 10^6 steps -- but the step size
+    grows to ~3 afterwards and 5 000 / 15 000 steps do.  During the transient the controller never rejects, which is what
+    tells it from a step size pinned by stability.  Same numbers as with a plain budget; a horizon the budget really
+    cannot cover (10^6: 100 000+ steps) and a genuinely exhausted plain budget are still reported."""
+    from sysbio_modeling_amd import models_zoo
+    m = gpu_models('cascade20')
+    _, P = models_zoo.cascade_ensemble(8)
+    for t_end in (3.0e4, 1.0e5):
+        t_out = np.array([0.0, 1.0e2, t_end])
+        S, Y = m.calc_jacobian_batch(P, t_out, return_states=True)                      # default: budget with early exit
+        info = {k: np.array(v, copy=True) for k, v in m.last_info.items() if k in ('status', 'n_steps')}
+        assert not info['status'].any() and info['n_steps'].max() < 50000
+        S2, Y2 = m.calc_jacobian_batch(P, t_out, return_states=True, max_steps=1000000)   # plain budget
+        assert np.array_equal(S, S2) and np.array_equal(Y, Y2) and np.array_equal(info['n_steps'], m.last_info['n_steps'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m.simulate_batch(P[:2], np.array([0.0, 1.0e6]))
+        assert m.last_info['status'].tolist() == [1, 1]
+        m.simulate_batch(P[:2], np.array([0.0, 1.0e2]), max_steps=100)
+        assert m.last_info['status'].tolist() == [1, 1]
+    # ... and method='auto' hands the long horizon to the implicit integrator
+    Ya = m.simulate_batch(P[:2], np.array([0.0, 1.0e6]), method='auto')
+    assert m.last_info['status'].tolist() == [0, 0] and m.last_info['stiff'].tolist() == [True, True]
+    Yl = m.simulate_batch(P[:2], np.array([0.0, 1.0e6]), max_steps=1000000)
+    assert parity_err(Ya[:, 1:], Yl[:, 1:]) <= 1.0

@@ -340,9 +340,9 @@ def test_more_state_variables_than_lanes():
     y0 = np.concatenate([0.2 + 0.01 * np.arange(n), rng.standard_normal(n * 18)])
     S_ic, Y_ic = m.calc_jacobian_batch(P[:1], np.array([0.0, 1.0]), init_conditions=y0, return_states=True)
     assert np.array_equal(Y_ic[0, 0], y0[:n]) and np.array_equal(S_ic[0, 0], y0[n:])
-    # the implicit kernel holds one state variable per lane: a clear error, and 'auto' runs without its fallback
-    with pytest.raises(Exception, match='n_vars <= 64'):
-        m.calc_jacobian_batch(P, t[idx], method='implicit_midpoint', n_steps=64)
+    # the implicit kernels take two state rows per lane as well (sbm_implicit_stepper.hpp): same solution
+    S_im = m.calc_jacobian_batch(P, t[idx], method='implicit_controlled')
+    assert m.last_info['status'].tolist() == [0, 0, 0] and parity_err(S_im[2], Sr[idx]) <= 1.0
     assert np.array_equal(m.calc_jacobian_batch(P, t[idx], method='auto'), res['auto'][0])
     assert not m.last_info['stiff'].any()
 
@@ -387,6 +387,11 @@ def test_three_state_rows_per_lane_against_finite_differences():
     # the fixed-step integrator on the same right-hand side lands on the same numbers
     S_rk = m.calc_jacobian_batch(p[None, :], t[idx], method='rk4', n_steps=4096)[0].reshape(len(idx), n, k)
     assert np.allclose(S_rk, S, rtol=1e-6, atol=1e-8 * np.abs(S).max())
+    # the implicit kernels keep a whole column of S per lane in registers: 128 state variables at most, a clear error
+    # beyond, and 'auto' runs without its fallback
+    with pytest.raises(Exception, match='n_vars <= 128'):
+        m.simulate_batch(p[None, :], t[idx], method='implicit_midpoint', n_steps=64)
+    assert np.array_equal(m.simulate_batch(p[None, :], t[idx], method='auto'), Y)
 
 
 def _random_network(seed, n):
