@@ -391,7 +391,8 @@ def test_three_state_rows_per_lane_against_finite_differences():
     # beyond, and 'auto' runs without its fallback
     with pytest.raises(Exception, match='n_vars <= 128'):
         m.simulate_batch(p[None, :], t[idx], method='implicit_midpoint', n_steps=64)
-    assert np.array_equal(m.simulate_batch(p[None, :], t[idx], method='auto'), Y)
+    assert np.array_equal(m.simulate_batch(p[None, :], t[idx], method='auto'), m.simulate_batch(p[None, :], t[idx]))
+    assert not m.last_info['status'].any()
 
 
 def _random_network(seed, n):
