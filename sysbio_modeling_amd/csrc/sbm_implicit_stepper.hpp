@@ -57,7 +57,7 @@ __device__ __forceinline__ double sbm_pick_slice(const double (&v)[N], int lane)
 
 // sizes of the factor tables in LDS
 template <class M>
-constexpr int sbm_imf_size() { return (M::IM_DIST ? M::NV * M::IM_LD : M::IM_NM) + 2; }
+constexpr int sbm_imf_size() { return (M::IM_DIST ? M::NV * M::IM_LD : M::IM_MF) + 2; }
 template <class M>
 constexpr int sbm_ird_size() { return M::IM_DIST ? M::NV : 1; }
 

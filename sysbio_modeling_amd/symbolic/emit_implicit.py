@@ -169,16 +169,20 @@ def emit_members(spec, d):
     # ---- distributed form for lower-triangular patterns ----
     L += ["  static constexpr bool IM_TRI = %s;" % ("true" if lower_only else "false")]
     if lower_only:
+        # every row's block [1 / M_ii, scaled entries...] starts at an EVEN index of the (16-byte aligned) table: the
+        # substitution reads a row's values in pairs, and a pair that straddles a 16-byte boundary costs a half-rate
+        # ds_read2_b64 instead of a ds_read_b128 (measured on stiff50: 209 -> 275 ms per pass of configs[4])
         rstart, pos = [], {}
         k = 0
         for i in range(n):
+            k += k & 1
             rstart.append(k)
             k += 1
             for (r, c) in pattern:
                 if r == i and c < i:
                     pos[(r, c)] = k
                     k += 1
-        assert k == nm
+        n_table = k
         L += ["  // MF layout: per row [1/M_ii, then gamma*J_ij/M_ii for j < i in column order]; b <- M^-1 b",
               "  __device__ __forceinline__ static void im_solve_tri(const double* mf, double (&b)[NV]) {"]
         for i in range(n):
@@ -191,9 +195,11 @@ def emit_members(spec, d):
                 # keep the compiler from hoisting every table load to the top (2*IM_NM live registers)
                 L.append("    SBM_LDS_FENCE();")
         L += ["  }"]
+        L += ["  static constexpr int IM_MF = %d;     // entries of the table (rows padded to even starts)" % n_table]
         L += emit_distributed(spec, d, pattern, ops)
-        return L, dict(tri=True, rstart=rstart, pos=pos, nm=nm)
-    L += ["  __device__ __forceinline__ static void im_solve_tri(const double*, double (&)[NV]) {}"]
+        return L, dict(tri=True, rstart=rstart, pos=pos, nm=n_table)
+    L += ["  __device__ __forceinline__ static void im_solve_tri(const double*, double (&)[NV]) {}",
+          "  static constexpr int IM_MF = IM_NM;"]
     L += emit_distributed(spec, d, pattern, ops)
     return L, dict(tri=False, nm=nm)
 
