@@ -269,6 +269,7 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
            "converged": int(fit['converged'].sum()), "cost_min": float(np.min(fit['cost'])),
            "cost_median": float(np.median(fit['cost'])),
            "cost_max": float(np.max(fit['cost'])), "evaluations": int(fit['n_evaluations']),
+           "evaluations_with_sensitivities": int(fit['n_jacobian_evaluations']),
            "starts_within_1pct_of_the_best_cost": int(np.sum(fit['cost'] <= 1.01 * np.min(fit['cost']))),
            "convergence_note": "the smallest singular value of the Jacobian at the optimum is 4e-20 (a sloppy model: some "
                                "parameter combinations are not constrained by the data at all), so leastsq's tests "

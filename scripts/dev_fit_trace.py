@@ -29,3 +29,17 @@ r = J['residuals'][0]
 g = Jm.T @ r
 sv = np.linalg.svd(Jm, compute_uv=False)
 print('gradient norm at the end', np.linalg.norm(g), 'cost', 0.5 * r @ r, 'singular values of J: max %.3g min %.3g' % (sv[0], sv[-1]))
+
+# eager against lazy Jacobians at several batch sizes
+import time
+import torch
+for n_starts in (256, 1024, 4096):
+    st = th0[None, :] + 0.15 * np.random.default_rng(2).standard_normal((n_starts, th0.size))
+    for lazy in (False, True):
+        proj.fit_batch(st[:8], max_iter=2, lazy_jacobian=lazy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f = proj.fit_batch(st, max_iter=30, lazy_jacobian=lazy)
+        torch.cuda.synchronize()
+        print("%5d starts, 30 iterations, lazy_jacobian=%s: %.3f s, %d evaluations, %d with sensitivities, median cost %.4f"
+              % (n_starts, lazy, time.perf_counter() - t0, f['n_evaluations'], f['n_jacobian_evaluations'], np.median(f['cost'])))

@@ -17,7 +17,8 @@ from .. import _lib
 
 
 def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambda_up=4.0, lambda_down=3.0,
-                              ftol=1.49012e-8, xtol=1.49012e-8, max_step=2.0, trace=False, **integrator_overrides):
+                              ftol=1.49012e-8, xtol=1.49012e-8, max_step=2.0, trace=False, lazy_jacobian='auto',
+                              **integrator_overrides):
     """Minimise 0.5 |r(theta)|^2 from every row of ``thetas0`` (V, q), independently.
 
     Marquardt damping per start: a step is accepted when the cost decreases (lambda /= lambda_down),
@@ -32,15 +33,27 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     (``max_steps``, default -20000: a budget of 20000 attempts which a trajectory gives up at once when its current
     step size could not finish within four budgets) -- a trial that exhausts it is simply rejected.
 
+    ``lazy_jacobian``: a trial point is first integrated WITHOUT sensitivities (the state-only kernels: a
+    tenth of the cost) to get its residuals; the state + sensitivity system is integrated only at the trial points that
+    were accepted -- MINPACK's economy (lmder evaluates the Jacobian once per successful step, the function once per
+    trial), batched: about half of the trials are rejected on a sloppy problem.  ``False``: one state + sensitivity
+    integration of every trial point per iteration.  'auto' (default): lazy from 8192 trajectories per iteration on (starts x
+    experiments) -- below that the chip is not full, a launch lasts as long as its longest trajectory whatever their
+    number, and two launches per iteration cost more than one (measured on the configs[3] project: 256 starts x 8
+    experiments 0.86 s eager / 0.97 s lazy per 100 iterations; see DESIGN.md section 6 for larger batches).
+
     With a handful of starts the chip is mostly empty: ``variant='small_batch'`` (an integrator override) lets the
     sensitivity kernel use its small-batch split while starts x experiments x chunks <= 1024.
 
     Returns a dict of numpy arrays: theta (V, q), cost (V,) = 0.5 |r|^2, n_iter (V,) iterations until
-    convergence (max_iter if never), converged (V,) bool, n_evaluations (total trial points integrated); with
+    convergence (max_iter if never), converged (V,) bool, n_evaluations (total trial points integrated),
+    n_jacobian_evaluations (those integrated with sensitivities); with
     ``trace=True`` also 'history': per iteration the number of accepted steps, starts still running, median cost,
     damping, relative decrease and largest step component (costs a device synchronisation per iteration).
     """
     import torch
+    if lazy_jacobian == 'auto':
+        lazy_jacobian = len(thetas0) * max(1, len(project._experiments)) >= 8192
     integrator_overrides.setdefault('max_steps', -20000)     # negative: budget with early exit (include/sbm.h)
     if project.reference_compat and project.n_total_rows != project.n_project_residuals:
         raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
@@ -77,6 +90,7 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     done = ~torch.isfinite(cost)                      # a start that cannot be integrated stays where it is
     n_iter = torch.full((V,), int(max_iter), dtype=torch.int64, device=dev)
     n_eval = V
+    n_jac = V                   # state + sensitivity integrations among them
     history = []
     p = _lib.dev_ptr
     for it in range(max_iter):
@@ -88,7 +102,12 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
         # enormous (and harmless) Gauss-Newton step, which must not scale everybody else's down to nothing
         delta = delta.clamp(-max_step, max_step)
         trial = torch.where(done[:, None], th, th + delta)
-        r_t, J_t, cost_t = evaluate(trial)
+        if lazy_jacobian:
+            out_t = project.evaluate_batch(trial, **integrator_overrides)
+            cost_t = 0.5 * out_t['norms']
+            cost_t = torch.where(torch.isfinite(cost_t) & (out_t['status'] == 0), cost_t, torch.full_like(cost_t, float('inf')))
+        else:
+            r_t, J_t, cost_t = evaluate(trial)
         n_eval += V
         ok = (st == 0) & (cost_t < cost) & ~done
         # MINPACK-style tests, on lightly damped steps only: a heavily damped step is short whatever the
@@ -98,10 +117,31 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
         # a negligible step ends the search whether or not it still lowers the cost (at the rounding floor it does not)
         small_x = (st == 0) & ~done & free & (delta.abs() <= xtol * (th.abs() + xtol)).all(dim=1)
         cost_prev = cost
-        th = torch.where(ok[:, None], trial, th)
-        r = torch.where(ok[:, None], r_t, r)
-        J = torch.where(ok[:, None, None], J_t, J)
-        cost = torch.where(ok, cost_t, cost)
+        if lazy_jacobian:
+            # residuals and Jacobian of the accepted points, from ONE integration each (so that J^T r is consistent)
+            sel = torch.nonzero(ok).flatten()
+            if sel.numel():
+                r_a, J_a, cost_a = evaluate(trial[sel])
+                n_jac += int(sel.numel())
+                # (the state-only and the state + sensitivity integrations agree to the integrator's tolerance, not to
+                # the bit: a point whose second integration fails or no longer improves stays where it was)
+                good = torch.isfinite(cost_a) & (cost_a < cost[sel])
+                sel, r_a, J_a, cost_a = sel[good], r_a[good], J_a[good], cost_a[good]
+                th[sel] = trial[sel]
+                r[sel] = r_a
+                J[sel] = J_a
+                cost = cost.clone()
+                cost[sel] = cost_a
+                ok = torch.zeros_like(ok)
+                ok[sel] = True
+            else:
+                ok = torch.zeros_like(ok)
+        else:
+            th = torch.where(ok[:, None], trial, th)
+            r = torch.where(ok[:, None], r_t, r)
+            J = torch.where(ok[:, None, None], J_t, J)
+            cost = torch.where(ok, cost_t, cost)
+            n_jac += V
         lam = torch.where(ok, lam / lambda_down, lam * lambda_up).clamp(1e-15, 1e15)
         newly = (small_f | small_x) & ~done
         if trace:
@@ -116,4 +156,5 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
             break
     return {'theta': th.cpu().numpy(), 'cost': cost.cpu().numpy(), 'n_iter': n_iter.cpu().numpy(),
             'converged': (done & torch.isfinite(cost)).cpu().numpy(), 'n_evaluations': n_eval,
+            'n_jacobian_evaluations': n_jac,
             **({'history': history} if trace else {})}
