@@ -147,6 +147,13 @@ def main(src, dst):
                     out['cycles_per_valu_inst'] = 4.0 * av['total'] / iv['total']
                     wc = e.get('SQ_WAVE_CYCLES')
                     wps = waves_per_simd(e['launch']['vgpr'], e['launch']['agpr'], e['launch']['lds'])
+                    # ... and no more than the launch has: a grid of fewer waves than the chip's 1024 SIMDs can hold
+                    try:
+                        n_waves = int(e['launch']['grid']) // 64
+                        if wps:
+                            wps = min(float(wps), n_waves / 1024.0)
+                    except (TypeError, ValueError):
+                        pass
                     if wc and wps:
                         out['waves_per_simd'] = wps
                         out['valu_active_share_of_wave_lifetime'] = av['total'] / wc['total']
