@@ -652,7 +652,8 @@ class Project(object):
                 t = th[torch.as_tensor(idx, device=th.device, dtype=torch.long)]
                 oi = _lib.implicit_adaptive_defaults(dict(method='implicit_adaptive', rtol=rtol, atol=atol),
                                                      set(integrator_overrides) | set(self.integrator_options))
-                return split(self._evaluate_once(t, jacobian, want, extrapolate=0, max_steps=0, **oi, **keep)) + (None,)
+                oi['max_steps'] = 0          # the budget belongs to the explicit attempt; the kernel's own limit here
+                return split(self._evaluate_once(t, jacobian, want, extrapolate=0, **oi, **keep)) + (None,)
             out, st, steps, stiff = _control.with_stiff_fallback(
                 lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=-budget,
                                                   rtol=rtol, atol=atol, extrapolate=0, **keep)),

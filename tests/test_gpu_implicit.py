@@ -304,6 +304,10 @@ def test_project_auto_method_on_the_stiff_model(gpu_models, golden):
     plain = proj.evaluate_batch(theta[1:], jacobian=True, want=('jacobian', 'model_jacobian'))
     assert np.array_equal(out['jacobian'][1], plain['jacobian'][0])
     assert np.array_equal(out['residuals'][1], plain['residuals'][0])
+    # DEFAULT options: the single-vector methods run 'auto' by themselves (what leastsq sees when a trial point is stiff)
+    r_def = proj.residuals(theta[0])
+    J_def = proj.calc_project_jacobian(theta[0])
+    assert np.all(np.isfinite(r_def)) and np.all(np.isfinite(J_def)) and r_def.shape == (48,) and J_def.shape == (48, 50)
     # the single-vector API of the reference takes the method from the project's options
     proj.integrator_options.update(method='auto', max_steps=20000)
     r = proj.residuals(theta[0])
@@ -313,6 +317,8 @@ def test_project_auto_method_on_the_stiff_model(gpu_models, golden):
     tau_s, _ = lsoda_taus(a, theta[0], out['sims'][0])
     tol = project_tolerances(a, out['sims'][0], np.zeros(0), tau_s)
     assert tol_ratio(r, out['residuals'][0], tol['residuals']) <= 1.0
+    assert tol_ratio(r_def, out['residuals'][0], tol['residuals']) <= 1.0
+    assert np.allclose(J_def, out['jacobian'][0], rtol=1e-6, atol=1e-8 * np.abs(J_def).max())
 
 
 STIFF_MOTIF = """
