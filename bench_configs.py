@@ -271,11 +271,11 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
            "cost_max": float(np.max(fit['cost'])), "evaluations": int(fit['n_evaluations']),
            "evaluations_with_sensitivities": int(fit['n_jacobian_evaluations']),
            "starts_within_1pct_of_the_best_cost": int(np.sum(fit['cost'] <= 1.01 * np.min(fit['cost']))),
+           "algorithm": "trust_region (MINPACK lmder, batched; sbm_lm_trust_step)",
            "convergence_note": "the smallest singular value of the Jacobian at the optimum is 4e-20 (a sloppy model: some "
                                "parameter combinations are not constrained by the data at all), so leastsq's tests "
-                               "(ftol = xtol = 1.49e-8) are not met within 100 iterations by either optimiser -- the cost "
-                               "still creeps down by 1e-5 per iteration along the flat directions; the fits are compared by "
-                               "the cost they reach",
+                               "(ftol = xtol = 1.49e-8) are met by few starts within 100 iterations -- the cost still creeps "
+                               "down along the flat directions; the fits are compared by the cost they reach",
            "distance_to_truth_max": float(np.max(np.abs(fit['theta'][fit['converged']] - th0[None, :])))
            if fit['converged'].any() else None}
     if cpu:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SBM_ABI_VERSION 2
+#define SBM_ABI_VERSION 3   /* 3: + sbm_lm_trust_step */
 
 typedef struct sbm_ctx sbm_ctx;
 typedef struct sbm_model sbm_model;
@@ -385,6 +385,25 @@ int sbm_loss_eval_host(sbm_ctx* ctx, const sbm_loss_desc* desc, int32_t V, const
 int sbm_lm_step(sbm_ctx* ctx, const double* J_dev, const double* r_dev, const double* lambda_dev,
                 int32_t V, int32_t M, int32_t q, double* delta_dev, double* pred_dev,
                 int32_t* status_dev);
+
+/* The same step with the damping chosen as MINPACK's lmder chooses it (lmpar, More 1978): given a scaling D and a
+ * trust-region radius Delta per vector, lambda >= 0 is found such that
+ *     (J^T J + lambda D^2) delta = -J^T r   and   | ||D delta|| - Delta | <= 0.1 Delta
+ * (lambda = 0 when the Gauss-Newton step is already inside) -- a safeguarded Newton iteration on the q x q system, a
+ * few Cholesky factorisations inside ONE launch instead of trial integrations with lambda multiplied up and down.
+ * dscale [V][q]  in / out  D: made max(D, column norm of J) here; zeros on the first call (MINPACK mode 1)
+ * radius [V]     in        Delta > 0
+ * lambda [V]     in / out  the previous parameter as a starting guess (0 on the first call) -> the one found
+ * delta  [V][q]  out       step
+ * pred   [V]     out       predicted decrease of 0.5 |r|^2 = 0.5 |J delta|^2 + lambda ||D delta||^2
+ * dxnorm [V]     out       ||D delta||
+ * status [V]     out       0, or 1: input not finite / no positive definite system found (delta = 0)
+ * What the caller does with them is lmder's bookkeeping (project/fitting.py, algorithm='trust_region'): ratio of actual
+ * to predicted reduction, radius update, acceptance.  Device pointers; q <= 128; enqueued on the context's stream.
+ * The reference fits with scipy.optimize.leastsq = MINPACK lmder (tests/test_Project.py:202-213, 351-357). */
+int sbm_lm_trust_step(sbm_ctx* ctx, const double* J_dev, const double* r_dev, double* dscale_dev,
+                      const double* radius_dev, double* lambda_dev, int32_t V, int32_t M, int32_t q,
+                      double* delta_dev, double* pred_dev, double* dxnorm_dev, int32_t* status_dev);
 
 /* ---- multi-GPU: the one exchange of the path ----------------------------- */
 /* The path shards by parameter vector with no data-path collective; what every

@@ -30,6 +30,17 @@ g = Jm.T @ r
 sv = np.linalg.svd(Jm, compute_uv=False)
 print('gradient norm at the end', np.linalg.norm(g), 'cost', 0.5 * r @ r, 'singular values of J: max %.3g min %.3g' % (sv[0], sv[-1]))
 
+# Marquardt up/down damping against the lmder trust region: cost reached per iteration count, 64 starts
+for algo in ('marquardt', 'trust_region'):
+    for n_it in (20, 50, 100, 200):
+        f = proj.fit_batch(starts, max_iter=n_it, algorithm=algo)
+        print("%-13s %3d iterations: cost min %.3f median %.3f max %.3f, converged %d, %d evaluations (%d with sensitivities); start #0: %.3f"
+              % (algo, n_it, f['cost'].min(), np.median(f['cost']), f['cost'].max(), int(f['converged'].sum()),
+                 f['n_evaluations'], f['n_jacobian_evaluations'], f['cost'][0]), flush=True)
+ft = proj.fit_batch(starts, max_iter=40, algorithm='trust_region', trace=True)
+for h in ft['history'][:40:3]:
+    print(h)
+sys.exit(0)
 # eager against lazy Jacobians at several batch sizes
 import time
 import torch

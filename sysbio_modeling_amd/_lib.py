@@ -13,7 +13,7 @@ from . import build
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
-ABI_VERSION = 2      # include/sbm.h: SBM_ABI_VERSION
+ABI_VERSION = 3      # include/sbm.h: SBM_ABI_VERSION
 SBM_RK4_FIXED = 0
 SBM_DOPRI45 = 1
 SBM_IMPLICIT_MIDPOINT = 2
@@ -87,6 +87,7 @@ SIGNATURES = {
     'sbm_project_scratch_bytes': (ctypes.c_int64, [_vp, _i32, _i32]),
     'sbm_allgather_norms': (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     'sbm_lm_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'sbm_lm_trust_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'sbm_loss_eval_host': (ctypes.c_int, [_vp, ctypes.POINTER(LossDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

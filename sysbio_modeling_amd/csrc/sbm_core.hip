@@ -1409,6 +1409,238 @@ extern "C" int sbm_lm_step(sbm_ctx* ctx, const double* J, const double* r, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// sbm_lm_trust_step: the Levenberg-Marquardt PARAMETER of a scaled trust region, per vector.
+//
+// What MINPACK's lmder does between two Jacobian evaluations (lmpar, More 1978), on the normal equations:
+// given the scaling D (the largest column norm of J seen so far, kept by the caller from call to call) and a radius
+// Delta, find lambda >= 0 with  (J^T J + lambda D^2) x = -J^T r  and  | ||D x|| - Delta | <= 0.1 Delta  (lambda = 0 if
+// the Gauss-Newton step is already inside), by More's safeguarded Newton iteration on
+// phi(lambda) = ||D x(lambda)|| - Delta:  lambda += (phi / Delta) / ||L^-1 D^2 x / ||D x||||^2  with L the Cholesky
+// factor of the damped matrix, kept between the bounds the iteration itself produces.  At most 10 factorisations of a
+// q x q matrix per call (two to three are the rule): microseconds, against the milliseconds of the integration that
+// follows -- which is why the search for lambda happens here, in one launch, rather than as a sequence of trial
+// INTEGRATIONS with lambda multiplied up and down (sbm_lm_step + project/fitting.py's 'marquardt' loop).
+// One 256-thread block per vector; J^T J in registers (the lower triangle, spread over the threads), the matrix being
+// factored in LDS.
+// ---------------------------------------------------------------------------------------------
+struct LmTrustArgs {
+  const double* J;       // [V][M][q]
+  const double* r;       // [V][M]
+  double* dscale;        // [V][q]  in / out: D, made max(D, column norm of J) here (0 on the first call)
+  const double* radius;  // [V]     Delta > 0
+  double* lambda;        // [V]     in: the previous parameter (a starting guess), out: the one found
+  double* delta;         // [V][q]  out: x
+  double* pred;          // [V]     out: predicted decrease of 0.5 |r|^2 = 0.5 x^T J^T J x + lambda ||D x||^2
+  double* dxnorm;        // [V]     out: ||D x||
+  int32_t* status;       // [V]     out: 0, or 1: non-finite input / no positive definite system found (x = 0)
+  int M, q;
+};
+
+// in-place Cholesky of the lower triangle of A (q x q, leading dimension ld) by the whole block; false if a pivot is
+// not positive (the decision is uniform: every thread reads the same pivot)
+__device__ __forceinline__ bool lm_cholesky(double* A, int q, int ld, int tid) {
+  for (int k = 0; k < q; ++k) {
+    const double piv = A[k * ld + k];
+    if (!(piv > 0.0) || !(piv < 1.0e300)) return false;
+    const double rp = 1.0 / sqrt(piv);
+    __syncthreads();
+    if (tid == 0) A[k * ld + k] = sqrt(piv);
+    for (int i = k + 1 + tid; i < q; i += 256) A[i * ld + k] *= rp;
+    __syncthreads();
+    const int nt = q - k - 1;
+    for (int e = tid; e < nt * nt; e += 256) {
+      const int i = k + 1 + e / nt, j = k + 1 + e % nt;
+      if (j <= i) A[i * ld + j] = fma(-A[i * ld + k], A[j * ld + k], A[i * ld + j]);
+    }
+    __syncthreads();
+  }
+  return true;
+}
+// x <- L^-1 x (column-oriented: one thread finishes x_i, all retire it from the rest)
+__device__ __forceinline__ void lm_forward(const double* A, double* x, int q, int ld, int tid) {
+  for (int i = 0; i < q; ++i) {
+    if (tid == 0) x[i] /= A[i * ld + i];
+    __syncthreads();
+    const double xi = x[i];
+    for (int j = i + 1 + tid; j < q; j += 256) x[j] = fma(-A[j * ld + i], xi, x[j]);
+    __syncthreads();
+  }
+}
+// x <- L^-T x
+__device__ __forceinline__ void lm_backward(const double* A, double* x, int q, int ld, int tid) {
+  for (int i = q - 1; i >= 0; --i) {
+    if (tid == 0) x[i] /= A[i * ld + i];
+    __syncthreads();
+    const double xi = x[i];
+    for (int j = tid; j < i; j += 256) x[j] = fma(-A[i * ld + j], xi, x[j]);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_lm_trust(LmTrustArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lm_smem[];
+  const int v = blockIdx.x, tid = threadIdx.x, q = a.q, M = a.M;
+  const int ld = q + 1;
+  double* A = lm_smem;                       // [q][ld]  the damped matrix / its Cholesky factor
+  double* D = A + (size_t)q * ld;            // [q]      scaling
+  double* g = D + q;                         // [q]      J^T r
+  double* x = g + q;                         // [q]      step
+  double* w = x + q;                         // [q]      work vector of the Newton correction
+  double* T = w + q;                         // [LM_TILE][ld] row tile of J
+  double* rt = T + (size_t)LM_TILE * ld;     // [LM_TILE]
+  __shared__ int s_bad;
+  __shared__ double s_red[4];
+  if (tid == 0) s_bad = 0;
+  const double* Jv = a.J + (size_t)v * M * q;
+  const double* rv = a.r + (size_t)v * M;
+  const int n_low = q * (q + 1) / 2;
+  constexpr int MAXOWN = (128 * 129 / 2 + 255) / 256;
+  double acc[MAXOWN];
+  int oi[MAXOWN], oj[MAXOWN];
+  int n_own = 0;
+  for (int e = tid; e < n_low; e += 256) {
+    int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    while (i * (i + 1) / 2 > e) --i;
+    oi[n_own] = i; oj[n_own] = e - i * (i + 1) / 2; acc[n_own] = 0.0; ++n_own;
+  }
+  double gacc = 0.0;
+  for (int m0 = 0; m0 < M; m0 += LM_TILE) {
+    const int rows = min(LM_TILE, M - m0);
+    __syncthreads();
+    for (int e = tid; e < rows * q; e += 256) {
+      const int rr = e / q, c = e - rr * q;
+      const double val = Jv[(size_t)(m0 + rr) * q + c];
+      T[rr * ld + c] = val;
+      if (!(fabs(val) < 1.0e300)) s_bad = 1;
+    }
+    for (int e = tid; e < rows; e += 256) {
+      const double val = rv[m0 + e];
+      rt[e] = val;
+      if (!(fabs(val) < 1.0e300)) s_bad = 1;
+    }
+    __syncthreads();
+    for (int k = 0; k < n_own; ++k) {
+      double sacc = acc[k];
+      for (int rr = 0; rr < rows; ++rr) sacc = fma(T[rr * ld + oi[k]], T[rr * ld + oj[k]], sacc);
+      acc[k] = sacc;
+    }
+    if (tid < q) {
+      double sacc = gacc;
+      for (int rr = 0; rr < rows; ++rr) sacc = fma(T[rr * ld + tid], rt[rr], sacc);
+      gacc = sacc;
+    }
+  }
+  __syncthreads();
+  const double Delta = a.radius[v];
+  double lam = a.lambda[v];
+  // scaling: the largest column norm seen so far (MINPACK mode 1); a column J never touches gets 1
+  for (int k = 0; k < n_own; ++k)
+    if (oi[k] == oj[k]) {
+      const double cn = sqrt(fmax(acc[k], 0.0));
+      double d = fmax(a.dscale[(size_t)v * q + oi[k]], cn);
+      if (!(d > 0.0)) d = 1.0;
+      D[oi[k]] = d;
+      a.dscale[(size_t)v * q + oi[k]] = d;
+    }
+  if (tid < q) g[tid] = gacc;
+  __syncthreads();
+  bool bad = s_bad != 0 || !(Delta > 0.0) || !(lam >= 0.0);
+  // paru = || D^-1 g || / Delta: with that much damping the step is inside the region
+  double part = 0.0;
+  if (tid < q) { const double t = g[tid] / D[tid]; part = t * t; }
+  const double gnorm = sqrt(block_sum(part, s_red));
+  double paru = gnorm / Delta;
+  if (!(paru > 0.0)) paru = 2.2e-308 / fmin(Delta, 0.1);
+  double parl = 0.0, fp = 0.0, dxn = 0.0;
+  bool have = false;
+
+  auto solve_with = [&](double par) -> bool {          // A <- chol(J^T J + par D^2); x <- -A^-1 g; dxn, fp
+    for (int k = 0; k < n_own; ++k) {
+      const int i = oi[k], j = oj[k];
+      A[i * ld + j] = (i == j) ? fma(par * D[i], D[i], acc[k]) : acc[k];
+    }
+    if (tid < q) x[tid] = -g[tid];
+    __syncthreads();
+    if (!lm_cholesky(A, q, ld, tid)) return false;
+    lm_forward(A, x, q, ld, tid);
+    lm_backward(A, x, q, ld, tid);
+    double p2 = 0.0;
+    if (tid < q) { const double t = D[tid] * x[tid]; p2 = t * t; }
+    dxn = sqrt(block_sum(p2, s_red));
+    fp = dxn - Delta;
+    return true;
+  };
+  auto newton_denominator = [&]() -> double {           // || L^-1 (D^2 x / dxn) ||^2 with the current factor
+    if (tid < q) w[tid] = D[tid] * D[tid] * x[tid] / dxn;
+    __syncthreads();
+    lm_forward(A, w, q, ld, tid);
+    double p2 = 0.0;
+    if (tid < q) p2 = w[tid] * w[tid];
+    return block_sum(p2, s_red);
+  };
+
+  if (!bad) {
+    // the Gauss-Newton step, if J has full rank numerically
+    if (solve_with(0.0)) {
+      if (fp <= 0.1 * Delta) { lam = 0.0; have = true; }
+      else { const double den = newton_denominator(); if (den > 0.0) parl = (fp / Delta) / den; }
+    }
+    if (!have) {
+      lam = fmin(fmax(lam, parl), paru);
+      if (lam == 0.0) lam = (dxn > 0.0) ? gnorm / dxn : 1.0e-3 * paru;
+      for (int it = 0; it < 10; ++it) {
+        if (lam == 0.0) lam = fmax(2.2e-308, 1.0e-3 * paru);
+        const double fp_old = fp;
+        if (!solve_with(lam)) {                        // rounding: not positive definite at this damping yet
+          parl = fmax(parl, lam);
+          lam = fmax(10.0 * lam, 1.0e-3 * paru);
+          if (lam > 1.0e3 * paru) break;               // (only non-finite data gets here)
+          continue;
+        }
+        have = true;
+        if (fabs(fp) <= 0.1 * Delta || (parl == 0.0 && fp <= fp_old && fp_old < 0.0) || it == 9) break;
+        const double den = newton_denominator();
+        const double parc = den > 0.0 ? (fp / Delta) / den : 0.0;
+        if (fp > 0.0) parl = fmax(parl, lam);
+        if (fp < 0.0) paru = fmin(paru, lam);
+        lam = fmax(parl, lam + parc);
+      }
+    }
+  }
+  if (bad || !have) {
+    for (int c = tid; c < q; c += 256) a.delta[(size_t)v * q + c] = 0.0;
+    if (tid == 0) { a.pred[v] = 0.0; a.dxnorm[v] = 0.0; a.status[v] = 1; }
+    return;
+  }
+  // predicted decrease of 0.5 |r|^2 under the Gauss-Newton model:  -g.x - 0.5 x^T H x  with  x^T H x = -g.x - lam dxn^2
+  double pp = 0.0;
+  if (tid < q) {
+    a.delta[(size_t)v * q + tid] = x[tid];
+    pp = -0.5 * g[tid] * x[tid];
+  }
+  const double tot = block_sum(pp, s_red) + 0.5 * lam * dxn * dxn;
+  if (tid == 0) { a.pred[v] = tot; a.dxnorm[v] = dxn; a.lambda[v] = lam; a.status[v] = 0; }
+}
+
+extern "C" int sbm_lm_trust_step(sbm_ctx* ctx, const double* J, const double* r, double* dscale, const double* radius,
+                                 double* lambda, int32_t V, int32_t M, int32_t q, double* delta, double* pred,
+                                 double* dxnorm, int32_t* status) {
+  if (!ctx || !J || !r || !dscale || !radius || !lambda || !delta || !pred || !dxnorm || !status)
+    return sbm_fail(SBM_E_ARG, "sbm_lm_trust_step: NULL argument");
+  if (V < 0 || M <= 0 || q <= 0 || q > 128) return sbm_fail(SBM_E_ARG, "sbm_lm_trust_step: bad sizes V=%d M=%d q=%d (q <= 128)", V, M, q);
+  if (V == 0) return 0;
+  SBM_HIP(hipSetDevice(ctx->device));
+  LmTrustArgs a{J, r, dscale, radius, lambda, delta, pred, dxnorm, status, M, q};
+  const size_t ld = (size_t)q + 1;
+  const size_t lds = sizeof(double) * (q * ld + 4 * q + LM_TILE * ld + LM_TILE);
+  if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_lm_trust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_lm_trust, dim3(V), dim3(256), lds, ctx->stream, a);
+  SBM_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The one collective of the path: all-gather of the per-vector residual norms.
 // RCCL is resolved at run time from whatever instance the process already has loaded -- the one that
 // created the caller's communicator -- so that libsbm_hip.so neither links RCCL nor brings a second copy

@@ -42,6 +42,59 @@ def test_lm_step_solves_damped_normal_equations():
     assert delta[3, 4] == 0.0
 
 
+def test_lm_trust_step_finds_the_levenberg_marquardt_parameter():
+    """sbm_lm_trust_step (MINPACK's lmpar on the device): on random systems the step solves
+    (J^T J + lambda D^2) delta = -J^T r with ||D delta|| within 10 % of the radius -- or lambda = 0 and the Gauss-Newton step
+    inside it -- D is the running maximum of the column norms, and the predicted decrease is that of the Gauss-Newton
+    model; a rank-deficient J is handled by the damping, non-finite input is reported."""
+    import torch
+    from sysbio_modeling_amd import _lib
+    rng = np.random.default_rng(3)
+    V, M, q = 9, 40, 12
+    J = rng.standard_normal((V, M, q)) * 10.0 ** rng.uniform(-3, 1, (V, 1, q))
+    r = rng.standard_normal((V, M))
+    J[2, :, 5] = 0.0                                   # a column nothing depends on
+    J[4, :, 7] = J[4, :, 3]                            # rank deficient
+    J[6, 1, 1] = np.inf                                # unusable
+    gn = np.array([np.linalg.norm(np.linalg.lstsq(J[v], -r[v], rcond=None)[0] * np.linalg.norm(J[v], axis=0))
+                   if v != 6 else 1.0 for v in range(V)])
+    radius = gn * np.array([10.0, 0.5, 0.3, 0.01, 0.2, 1e-4, 1.0, 2.0, 0.05])      # some inside, most outside
+    d_in = np.zeros((V, q))
+    d_in[1] = 3.0 * np.linalg.norm(J[1], axis=0)       # a larger scaling from earlier iterations stays
+    lam_in = np.zeros(V)
+    lam_in[3] = 7.0                                    # a poor starting guess
+    dev = 'cuda'
+    Jd, rd, Dd, Rd, Ld = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (J, r, d_in, radius, lam_in))
+    delta = torch.empty((V, q), dtype=torch.float64, device=dev)
+    pred = torch.empty((V,), dtype=torch.float64, device=dev)
+    dxn = torch.empty((V,), dtype=torch.float64, device=dev)
+    st = torch.empty((V,), dtype=torch.int32, device=dev)
+    ctx = _lib.default_context()
+    p = _lib.dev_ptr
+    _lib.check(ctx.lib.sbm_lm_trust_step(ctx.handle, p(Jd), p(rd), p(Dd), p(Rd), p(Ld), V, M, q, p(delta), p(pred), p(dxn),
+                                         p(st)), 'sbm_lm_trust_step')
+    torch.cuda.synchronize()
+    delta, pred, dxn, st, D, lam = (x.cpu().numpy() for x in (delta, pred, dxn, st, Dd, Ld))
+    assert st.tolist() == [0, 0, 0, 0, 0, 0, 1, 0, 0] and np.all(delta[6] == 0)
+    for v in range(V):
+        if v == 6:
+            continue
+        cn = np.linalg.norm(J[v], axis=0)
+        want_D = np.maximum(d_in[v], cn)
+        want_D[want_D == 0] = 1.0
+        assert np.allclose(D[v], want_D, rtol=1e-13)
+        A, g = J[v].T @ J[v], J[v].T @ r[v]
+        assert lam[v] >= 0.0
+        assert np.allclose((A + lam[v] * np.diag(D[v] ** 2)) @ delta[v], -g, rtol=1e-7, atol=1e-9 * np.abs(g).max())
+        assert dxn[v] == pytest.approx(np.linalg.norm(D[v] * delta[v]), rel=1e-10)
+        if lam[v] == 0.0:
+            assert dxn[v] <= 1.1 * radius[v]
+        else:
+            assert abs(dxn[v] - radius[v]) <= 0.1 * radius[v] * (1 + 1e-9)
+        assert pred[v] == pytest.approx(-(g @ delta[v]) - 0.5 * delta[v] @ A @ delta[v], rel=1e-7, abs=1e-12)
+    assert lam[0] == 0.0 and lam[7] == 0.0 and np.all(lam[[1, 2, 3, 5, 8]] > 0)
+
+
 def _exact_simple_project(m, theta_true, sf_groups=None):
     """Two experiments of the one-state model (shared k_synt, one k_deg each: the structure of
     tests/test_Project.py:27-72) with data the model itself produces at ``theta_true``."""
@@ -60,7 +113,8 @@ def _exact_simple_project(m, theta_true, sf_groups=None):
     return Project(m, exps, settings, {'Variable_1': ('direct', 0)}, sf_groups=sf_groups, reference_compat=False)
 
 
-def test_multi_start_fit_matches_leastsq(gpu_models):
+@pytest.mark.parametrize('algorithm', ['trust_region', 'marquardt'])
+def test_multi_start_fit_matches_leastsq(gpu_models, algorithm):
     """The reference fits with leastsq(proj.residuals, x0, Dfun=proj.calc_project_jacobian)
     (tests/test_Project.py:202-213).  Same call through this package's Project (batch of one), and 64
     starts at once with fit_batch: all reach the parameters that generated the data."""
@@ -77,7 +131,7 @@ def test_multi_start_fit_matches_leastsq(gpu_models):
     rng = np.random.default_rng(5)
     starts = truth[None, :] + rng.uniform(-1.0, 1.0, (64, 3))
     starts[0] = x0
-    fit = proj.fit_batch(starts, max_iter=60)
+    fit = proj.fit_batch(starts, max_iter=60, algorithm=algorithm)
     assert fit['converged'].all()
     assert np.allclose(fit['theta'], truth[None, :], atol=1e-6)
     assert fit['cost'].max() < 1e-14
@@ -86,7 +140,8 @@ def test_multi_start_fit_matches_leastsq(gpu_models):
     assert info['nfev'] >= 4          # leastsq needed several serial evaluations for ONE start
 
 
-def test_fit_batch_on_the_config4_project(gpu_models):
+@pytest.mark.parametrize('algorithm', ['trust_region', 'marquardt'])
+def test_fit_batch_on_the_config4_project(gpu_models, algorithm):
     """configs[3]-style project (8 experiments, 512 rows, 68 parameters, 4 free scale factors) with
     noise-free data: a sloppy problem (rate constants and scale factors trade off), so the test is on the
     cost, not on the parameters: 32 starts scattered around the truth, 40 iterations = 41 batched
@@ -99,7 +154,7 @@ def test_fit_batch_on_the_config4_project(gpu_models):
         assert proj.calc_sum_square_residuals(th0) < 1e-12
         starts = th0[None, :] + 0.15 * np.random.default_rng(1).standard_normal((32, th0.size))
         c0 = proj.calc_sum_square_residuals_batch(starts)
-        fit = proj.fit_batch(starts, max_iter=40)
+        fit = proj.fit_batch(starts, max_iter=40, algorithm=algorithm)
     assert fit['n_evaluations'] == 32 * 41
     assert np.all(fit['cost'] <= c0)
     assert np.median(fit['cost']) < 1e-5 * np.median(c0)

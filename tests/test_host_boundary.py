@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libsbm_hip.so does not export %s" % name
         assert name in _lib.SIGNATURES, "python binding has no signature for %s" % name
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.sbm_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.sbm_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header(tmp_path):
