@@ -278,6 +278,16 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
                                "down along the flat directions; the fits are compared by the cost they reach",
            "distance_to_truth_max": float(np.max(np.abs(fit['theta'][fit['converged']] - th0[None, :])))
            if fit['converged'].any() else None}
+    # round 1's multiplicative damping on the same starts, for the record
+    proj.fit_batch(starts[:8], max_iter=3, algorithm='marquardt')
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    fit_m = proj.fit_batch(starts, max_iter=100, ftol=1.49012e-8, xtol=1.49012e-8, algorithm='marquardt')
+    torch.cuda.synchronize(dev)
+    out["algorithm_marquardt"] = {"seconds": time.perf_counter() - t0, "cost_min": float(np.min(fit_m['cost'])),
+                                  "cost_median": float(np.median(fit_m['cost'])), "cost_max": float(np.max(fit_m['cost'])),
+                                  "converged": int(fit_m['converged'].sum()),
+                                  "note": "sbm_lm_step + lambda multiplied up / down by trial integrations (round 1)"}
     if cpu:
         from scipy.optimize import leastsq
         from oracle.project_oracle import ProjectOracle

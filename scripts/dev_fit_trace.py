@@ -30,16 +30,26 @@ g = Jm.T @ r
 sv = np.linalg.svd(Jm, compute_uv=False)
 print('gradient norm at the end', np.linalg.norm(g), 'cost', 0.5 * r @ r, 'singular values of J: max %.3g min %.3g' % (sv[0], sv[-1]))
 
-# Marquardt up/down damping against the lmder trust region: cost reached per iteration count, 64 starts
-for algo in ('marquardt', 'trust_region'):
-    for n_it in (20, 50, 100, 200):
-        f = proj.fit_batch(starts, max_iter=n_it, algorithm=algo)
-        print("%-13s %3d iterations: cost min %.3f median %.3f max %.3f, converged %d, %d evaluations (%d with sensitivities); start #0: %.3f"
-              % (algo, n_it, f['cost'].min(), np.median(f['cost']), f['cost'].max(), int(f['converged'].sum()),
-                 f['n_evaluations'], f['n_jacobian_evaluations'], f['cost'][0]), flush=True)
-ft = proj.fit_batch(starts, max_iter=40, algorithm='trust_region', trace=True)
-for h in ft['history'][:40:3]:
-    print(h)
+# Marquardt up/down damping against the lmder trust region: cost reached and time, 256 starts x 100 iterations
+import time
+import torch
+starts256 = th0[None, :] + 0.15 * np.random.default_rng(1).standard_normal((256, th0.size))
+for label, kw in (('marquardt', dict(algorithm='marquardt')),
+                  ('trust_region, clip 2, factor 100', dict(algorithm='trust_region')),
+                  ('trust_region, clip 20, factor 100', dict(algorithm='trust_region', max_step=20.0)),
+                  ('trust_region, clip 2, factor 1', dict(algorithm='trust_region', factor=1.0)),
+                  ('trust_region, clip 2, factor 0.1', dict(algorithm='trust_region', factor=0.1)),
+                  ('trust_region, clip 1, factor 1', dict(algorithm='trust_region', factor=1.0, max_step=1.0)),
+                  ('trust_region, clip 2, factor 1, budget 5000', dict(algorithm='trust_region', factor=1.0, max_steps=-5000))):
+    proj.fit_batch(starts256[:8], max_iter=2, **kw)
+    for n_it in (30, 100):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f = proj.fit_batch(starts256, max_iter=n_it, **kw)
+        torch.cuda.synchronize()
+        print("%-44s %3d iterations %.2f s: cost min %.3f median %.3f max %.3f, converged %d; start #0: %.3f"
+              % (label, n_it, time.perf_counter() - t0, f['cost'].min(), np.median(f['cost']), f['cost'].max(),
+                 int(f['converged'].sum()), f['cost'][0]), flush=True)
 sys.exit(0)
 # eager against lazy Jacobians at several batch sizes
 import time

@@ -16,6 +16,21 @@ import numpy as np
 from .. import _lib
 
 
+def _trial_budget(project, th, integrator_overrides):
+    """Step budget of the TRIAL integrations when the caller named none: five times what the starting points need (at
+    least 2000 attempts), with the early exit (negative ``max_steps``, include/sbm.h).  One launch lasts as long as its
+    slowest trajectory, and an optimiser free to wander along unconstrained parameter directions finds regions where
+    the model is stiff and a trajectory takes 20 times the usual steps: such a trial point is worth rejecting by its
+    price alone -- the trust region then shrinks away from it.  (Measured on the sloppy configs[3] project, 256 starts
+    x 100 iterations of the trust-region algorithm: 4.4 s with a budget of 20 000 attempts, 1.7 s with 5 000, same costs.)"""
+    if 'max_steps' in integrator_overrides:
+        return
+    out = project.evaluate_batch(th, want=('n_steps',), **integrator_overrides)
+    # ('n_steps' is the SUM over a vector's trajectories, one per experiment)
+    typical = float(out['n_steps'].max()) / max(1, len(project._experiments)) if out['n_steps'].numel() else 0.0
+    integrator_overrides['max_steps'] = -max(2000, int(5.0 * typical))
+
+
 def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambda_up=4.0, lambda_down=3.0,
                               ftol=1.49012e-8, xtol=1.49012e-8, max_step=2.0, trace=False, lazy_jacobian='auto',
                               algorithm='trust_region', factor=100.0, **integrator_overrides):
@@ -37,8 +52,8 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     Failed integrations (inf cost) count as rejections.  Two safeguards keep wild trial points from
     stalling the whole batch (one launch waits for its slowest trajectory): every component of a step is
     clipped to ``max_step`` log-units, and trial integrations get a step budget
-    (``max_steps``, default -20000: a budget of 20000 attempts which a trajectory gives up at once when its current
-    step size could not finish within four budgets) -- a trial that exhausts it is simply rejected.
+    (``max_steps``; default: five times what the starting points need, `_trial_budget`) -- a trial that exhausts it is
+    simply rejected.
 
     ``lazy_jacobian``: a trial point is first integrated WITHOUT sensitivities (the state-only kernels: a
     tenth of the cost) to get its residuals; the state + sensitivity system is integrated only at the trial points that
@@ -61,12 +76,11 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     import torch
     if algorithm in ('trust_region', 'lmder', 'minpack'):
         return _trust_region_batch(project, thetas0, max_iter=max_iter, ftol=ftol, xtol=xtol, factor=factor, trace=trace,
-                                   lazy_jacobian=lazy_jacobian, **integrator_overrides)
+                                   lazy_jacobian=lazy_jacobian, max_step=max_step, **integrator_overrides)
     if algorithm != 'marquardt':
         raise ValueError("fit_batch: unknown algorithm %r ('marquardt' or 'trust_region')" % (algorithm,))
     if lazy_jacobian == 'auto':
         lazy_jacobian = len(thetas0) * max(1, len(project._experiments)) >= 8192
-    integrator_overrides.setdefault('max_steps', -20000)     # negative: budget with early exit (include/sbm.h)
     if project.reference_compat and project.n_total_rows != project.n_project_residuals:
         raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
                          "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
@@ -74,6 +88,7 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     ctx = project._model.device_model.ctx      # the context (device, stream) the project's model lives on
     th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
     th = th.clone()
+    _trial_budget(project, th, integrator_overrides)
     dev = th.device
     V, q = th.shape
     f64, i32 = torch.float64, torch.int32
@@ -173,7 +188,7 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
 
 
 def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.49012e-8, factor=100.0, trace=False,
-                        lazy_jacobian='auto', max_step=20.0, **integrator_overrides):
+                        lazy_jacobian='auto', max_step=2.0, **integrator_overrides):
     """MINPACK's lmder for V starts at once -- the optimiser behind the reference's ``scipy.optimize.leastsq`` calls
     (tests/test_Project.py:202-213, 351-357), with its bookkeeping as tensor selects and its inner problem (lmpar: the
     Levenberg-Marquardt parameter of a scaled trust region) solved per start on the device (``sbm_lm_trust_step``, one
@@ -188,7 +203,6 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
     that cannot be integrated counts as an increase of the cost.  ``max_step`` only keeps exp(theta) finite.
     """
     import torch
-    integrator_overrides.setdefault('max_steps', -20000)
     if project.reference_compat and project.n_total_rows != project.n_project_residuals:
         raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
                          "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
@@ -198,6 +212,7 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
     ctx = project._model.device_model.ctx
     th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
     th = th.clone()
+    _trial_budget(project, th, integrator_overrides)
     dev = th.device
     V, q = th.shape
     f64, i32 = torch.float64, torch.int32
