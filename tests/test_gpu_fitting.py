@@ -224,3 +224,37 @@ def test_sampler_with_recalculated_hessian(gpu_models):
     pooled = ens[60:].reshape(-1, 2)
     assert np.all(np.abs(pooled.mean(axis=0) - truth) < 0.12 * sd)
     assert np.allclose(pooled.std(axis=0), sd, rtol=0.15)
+
+
+def test_fit_and_sampler_on_a_model_with_its_own_context(gpu_models):
+    """A model enabled on an explicit Context (what bench.py does per rank: `model.enable_jit(_lib.Context(local_rank))`)
+    is fitted and sampled through THAT context's handle -- the optimiser's device calls (sbm_lm_trust_step, sbm_lm_step)
+    take the context of the project's model, not the process default -- with the same numbers as on the default one."""
+    from sysbio_modeling_amd import _lib
+    from sysbio_modeling_amd.model import OdeModel
+    from sysbio_modeling_amd.symbolic import zoo_model
+    from sysbio_modeling_amd.project.ensembles import ensemble_log_params_batch
+    gm = zoo_model('simple')
+    own = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='simple')
+    ctx = _lib.Context(0)
+    own.enable_jit(ctx)
+    assert own.device_model.ctx is ctx and ctx is not _lib.default_context()
+    truth = np.log([0.05, 0.02, 0.3])
+    starts = None
+    results = []
+    for m in (own, gpu_models('simple')):
+        proj = _exact_simple_project(m, truth)
+        th = np.zeros(3)
+        th[proj.get_param_index('Group_1', ('High',))] = truth[0]
+        th[proj.get_param_index('Group_1', ('Low',))] = truth[1]
+        th[proj.get_param_index('k_synt', 'Global')] = truth[2]
+        if starts is None:
+            starts = th[None, :] + np.random.default_rng(2).uniform(-0.5, 0.5, (8, 3))
+        fits = [proj.fit_batch(starts, max_iter=25, algorithm=a) for a in ('trust_region', 'marquardt')]
+        ens = ensemble_log_params_batch(proj, np.tile(th, (4, 1)), steps=5, seeds=9)[0]
+        results.append((fits[0]['theta'], fits[1]['theta'], ens))
+        assert np.allclose(fits[0]['theta'], th[None, :], atol=1e-6) and np.allclose(fits[1]['theta'], th[None, :], atol=1e-6)
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+    own.disable_jit()
+    ctx.close()
