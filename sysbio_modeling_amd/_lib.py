@@ -196,7 +196,10 @@ def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_st
 # contexts and models
 # ---------------------------------------------------------------------------
 class Context(object):
-    """One per device (per thread of use).  ``stream``: raw hipStream_t handle or None."""
+    """One per device (per thread of use).  ``stream``: raw hipStream_t handle or None (the null stream, which is also
+    torch's default stream: the Python classes of this package allocate and post-process with torch on torch's CURRENT
+    stream and launch the library's kernels on the context's, so a context on another stream is for callers of the C
+    ABI who order the two themselves -- or run the Python classes under ``torch.cuda.stream(ExternalStream(handle))``)."""
 
     def __init__(self, device=0, stream=None):
         self.lib = load_library()
