@@ -224,11 +224,21 @@ static int check_model_fits(const sbm_model* m, const sbm_integrator_opts& o, co
   return 0;
 }
 
+static int launch_failed(sbm_model* m, const sbm_integrator_opts& o, int e, const char* who) {
+  if (e == (int)hipErrorInvalidConfiguration &&
+      (o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED || o.method == SBM_IMPLICIT_ADAPTIVE))
+    return sbm_fail(SBM_E_ARG, "%s: model '%s' (%d state variables, %d sensitivity columns) does not fit the implicit kernel "
+                    "asked for: its tables need more than the 160 KB of LDS of a compute unit (the error-controlled kernel "
+                    "parks two copies of a 64-column block of S there); the fixed-step method may still fit", who,
+                    m->info.name, m->info.n_vars, m->info.n_sens);
+  return sbm_fail(SBM_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString((hipError_t)e));
+}
+
 static int launch(sbm_model* m, int kind, const sbm_kernel_args& a, const char* who) {
   if (int rc = check_model_fits(m, a.opts, who)) return rc;
   SBM_HIP(hipSetDevice(m->ctx->device));
   int e = m->launch(kind, &a, (void*)m->ctx->stream);
-  if (e != 0) return sbm_fail(SBM_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString((hipError_t)e));
+  if (e != 0) return launch_failed(m, a.opts, e, who);
   return 0;
 }
 
@@ -286,7 +296,7 @@ static int launch_sens(sbm_model* m, sbm_kernel_args a, const char* who) {
     if (!a.n_reject) a.n_reject = m->cost_rej.p;
   }
   int e = m->launch(SBM_KIND_SENS, &a, (void*)s);
-  if (e != 0) return sbm_fail(SBM_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString((hipError_t)e));
+  if (e != 0) return launch_failed(m, a.opts, e, who);
   if (use) {
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s, a.n_steps, a.n_reject, T, m->order.p);
     SBM_HIP(hipGetLastError());
