@@ -359,6 +359,15 @@ def variant_extras(model, dev, theta_p, tg, rk4_steps):
         ex["sens_dopri45_%s" % variant] = t(_lib.make_opts('dopri45', rtol=1e-9, atol=1e-12, variant=variant))
         ex["sens_rk4_fixed_%d_%s" % (rk4_steps, variant)] = t(_lib.make_opts('rk4', n_steps=rk4_steps, t_end=100.0,
                                                                              variant=variant))
+    # the eighth-order pair on the headline workload at OdeModel's default tolerances (rtol cut by ten for it, as the
+    # Python classes do: _lib.implicit_adaptive_defaults) next to DOPRI45 at the same defaults: the pass, not steps/s, is
+    # what a fit waits for
+    tol = {k: model.integrator_options[k] for k in ('rtol', 'atol')}
+    ex["sens_dopri45_default_tolerances"] = t(_lib.make_opts('dopri45', **tol))
+    ex["sens_dop853_default_tolerances"] = dict(t(_lib.make_opts('dop853', rtol=0.1 * tol['rtol'], atol=tol['atol'])),
+                                                note="DOP853 (SBM_DOP853): twelve stages per step, a seventh of the steps; "
+                                                     "same parity tests as DOPRI45 (tests/test_gpu_dop853.py)")
+    ex["sens_dop853_rtol1e-9_atol1e-12"] = t(_lib.make_opts('dop853', rtol=1e-9, atol=1e-12))
     # the reference's own fixture size: Michaelis-Menten (2 states, 5 parameters: 12 coupled ODEs), 4096 vectors with
     # sensitivities -- one trajectory per wavefront (row-group / row-lane) against eight per wavefront (packed)
     try:

@@ -66,13 +66,19 @@ enum {
    * vectors DOPRI45 gives up on -- the role of LSODA's own switch to BDF (model/ode_model.py:122-123).  n_steps
    * counts the coarse steps of the accepted pass (each goes with 2 + 4 finer steps: seven midpoint solves),
    * n_reject those of the abandoned passes. */
-  SBM_IMPLICIT_ADAPTIVE = 4
+  SBM_IMPLICIT_ADAPTIVE = 4,
+  /* Dormand-Prince 8(5,3) (DOP853): twelve stages per step, error control as DOPRI45 (Hairer's combination of the
+   * fifth- and third-order embedded estimates), for TIGHT tolerances -- at the default rtol 1e-9 a seventh of
+   * DOPRI45's steps and a third of its right-hand-side evaluations on the 20-state model with sensitivities.  Runs on
+   * the row-group sensitivity kernels and the state-rows / packed state kernels (models whose rows the generator could
+   * split: sbm_model_info; others answer SBM_E_ARG).  opts.variant: AUTO or SMALL_BATCH. */
+  SBM_DOP853 = 5
 };
 
 typedef struct sbm_integrator_opts {
-  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_IMPLICIT_MIDPOINT[_GRADED] | SBM_IMPLICIT_ADAPTIVE */
+  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_DOP853 | SBM_IMPLICIT_MIDPOINT[_GRADED] | SBM_IMPLICIT_ADAPTIVE */
   int32_t max_steps; /* per trajectory, accepted + rejected; 0 -> 1000000.  DOPRI45, negative: a budget of
-                      * |max_steps| with an early exit (status SBM_MAX_STEPS at once) for a trajectory whose
+                      * (and DOP853) |max_steps| with an early exit (status SBM_MAX_STEPS at once) for a trajectory whose
                       * current step size would need more than four budgets for the remaining time span --
                       * checked every 256 attempts from the 512th on, and only while the step size has stopped
                       * growing from one check to the next: the explicit method on a stiff system */

@@ -1,0 +1,75 @@
+"""Developer timing: DOP853 against DOPRI45 on the headline workload (4096 vectors of cascade20 with sensitivities) at the
+default tolerances -- pass time, steps, and the distance of both from a tight solution on a few vectors."""
+import os, sys, time, warnings
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+warnings.simplefilter('ignore')
+import torch
+from sysbio_modeling_amd import models_zoo
+from sysbio_modeling_amd.model import OdeModel
+from sysbio_modeling_amd.symbolic import zoo_model
+from oracle import odeint_oracle as oo
+from oracle.tolerances import parity_err, survey_err
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'cascade20'
+if name == 'cascade20':
+    gm = zoo_model('cascade20')
+else:      # a forced row split (built beforehand with SBM_RG_FORCE_PLAN set: the generated text is cached by name)
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    gm = GeneratedModel(models_zoo.cascade_spec(20, name=name))
+gm.c_library()
+m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=name)
+print('model', name)
+_, P = models_zoo.cascade_ensemble(4096)
+grid = np.linspace(0, 100.0, 1000)
+idx = np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)
+t_out = np.concatenate([[0.0], grid[idx]])
+Pd, td = P, t_out          # (host arrays: the batch methods of OdeModel stage them; the timing includes that)
+res = {}
+for method in ('dopri45', 'dop853'):
+    for kw in ({}, dict(rtol=1e-9, atol=1e-12), dict(rtol=1e-7, atol=1e-12)):
+        S, Y = m.calc_jacobian_batch(Pd, td, return_states=True, method=method, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            S, Y = m.calc_jacobian_batch(Pd, td, return_states=True, method=method, **kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        info = m.last_info
+        print("%-8s %-28s %.2f ms per pass, %d accepted steps (%.0f per vector), %d rejected, failed %d"
+              % (method, kw or 'default tolerances', dt * 1e3, int(info['n_steps'].sum()), info['n_steps'].mean(),
+                 int(info['n_rejected'].sum()), int(np.count_nonzero(info['status']))), flush=True)
+        if not kw:
+            res[method] = (np.asarray(S[:4]), np.asarray(Y[:4]))
+for v in range(4):
+    tight = oo.tight_solution(gm, P[v], t_out, use_c=True, atol=1e-30)[1:]
+    for method in ('dopri45', 'dop853'):
+        S, Y = res[method]
+        print("vector %d %-8s vs tight (section 8(d) units): state %.3f sens %.3f" % (v, method, survey_err(Y[v, 1:], tight[:, :20]), survey_err(S[v, 1:], tight[:, 20:])), flush=True)
+# kernel time alone (device-resident buffers, as bench.py times the integrator)
+from sysbio_modeling_amd import _lib
+dm = m.device_model
+Pt = torch.from_numpy(P).cuda(); tt = torch.from_numpy(t_out).cuda()
+Yk = torch.empty((4096, len(t_out), 20), dtype=torch.float64, device='cuda')
+Sk = torch.empty((4096, len(t_out), 20, 40), dtype=torch.float64, device='cuda')
+nk = torch.empty((4096,), dtype=torch.int32, device='cuda')
+for method in ('dopri45', 'dop853'):
+    for kw in (dict(rtol=m.integrator_options['rtol'], atol=m.integrator_options['atol']), dict(rtol=1e-9, atol=1e-12), dict(rtol=1e-7, atol=1e-10)):
+        o = _lib.make_opts(method, **kw)
+        dm.sens_dev(Pt, tt, None, o, Yk, Sk, None, nk, None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dm.sens_dev(Pt, tt, None, o, Yk, Sk, None, nk, None)
+        e1.record(); torch.cuda.synchronize()
+        print("kernel %-8s rtol %.0e atol %.0e: %.3f ms, %.0f steps per vector" % (method, kw['rtol'], kw['atol'], e0.elapsed_time(e1) / 5, nk.float().mean().item()), flush=True)
+# state only
+for method in ('dopri45', 'dop853'):
+    Y = m.simulate_batch(Pd, td, method=method)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        Y = m.simulate_batch(Pd, td, method=method)
+    torch.cuda.synchronize()
+    print("state only %-8s %.3f ms per pass, %.0f steps per vector" % (method, (time.perf_counter() - t0) / 3 * 1e3, m.last_info['n_steps'].mean()))

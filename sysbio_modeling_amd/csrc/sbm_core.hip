@@ -203,7 +203,7 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
   if (!o) return sbm_fail(SBM_E_ARG, "%s: opts is NULL", who);
   if (o->method == SBM_RK4_FIXED) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: RK4 needs h0 > 0", who);
-  } else if (o->method == SBM_DOPRI45 || o->method == SBM_IMPLICIT_ADAPTIVE) {
+  } else if (o->method == SBM_DOPRI45 || o->method == SBM_DOP853 || o->method == SBM_IMPLICIT_ADAPTIVE) {
     if (!(o->rtol > 0.0) || !(o->atol > 0.0)) return sbm_fail(SBM_E_ARG, "%s: adaptive methods need rtol, atol > 0", who);
   } else if (o->method == SBM_IMPLICIT_MIDPOINT || o->method == SBM_IMPLICIT_MIDPOINT_GRADED) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: implicit midpoint needs h0 > 0", who);
@@ -231,6 +231,9 @@ static int launch_failed(sbm_model* m, const sbm_integrator_opts& o, int e, cons
                     "asked for: its tables need more than the 160 KB of LDS of a compute unit (the error-controlled kernel "
                     "parks two copies of a 64-column block of S there); the fixed-step method may still fit", who,
                     m->info.name, m->info.n_vars, m->info.n_sens);
+  if (e == (int)hipErrorInvalidConfiguration && o.method == SBM_DOP853)
+    return sbm_fail(SBM_E_ARG, "%s: DOP853 runs on the row-group sensitivity kernels and the state-rows kernels; model '%s' "
+                    "has no row split (or more than 256 state variables): use DOPRI45", who, m->info.name);
   return sbm_fail(SBM_E_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString((hipError_t)e));
 }
 

@@ -446,7 +446,8 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
     rl_tables, rl_meta = emit_rowlane.emit_rowlane_tables(spec, d, None)
     rg_tables, rg_layout = emit_rowgroup.emit_tables(spec, d, tag='RG0')
     rg_tables1, rg_layout1 = emit_rowgroup.emit_tables(spec, d, tag='RG1', latency=True)
-    rg_tables = rg_tables + rg_tables1
+    rg_tables2, rg_layout2 = emit_rowgroup.emit_tables(spec, d, tag='RG2', dop853=True)
+    rg_tables = rg_tables + rg_tables1 + rg_tables2
     im_members, im_meta = emit_implicit.emit_members(spec, d)
     im_tables = emit_implicit.emit_tables(spec, d, im_meta)
     L += ["#pragma once", ""] + rl_tables + rg_tables + im_tables + [
@@ -539,6 +540,7 @@ def emit_hip(spec: ModelSpec, derived: Derived = None) -> str:
                                            lambda smap: _ExprPrinter(smap, rcp="SBM_RCP(%s)", lang='hip'))
     L += [""] + emit_rowgroup.emit_members(spec, d, rg_layout, tag='RG0')
     L += emit_rowgroup.emit_members(spec, d, rg_layout1, tag='RG1', alias_of='RG0')
+    L += emit_rowgroup.emit_members(spec, d, rg_layout2, tag='RG2', alias_of='RG0')
     L += [""] + im_members + [
         "  __device__ __forceinline__ static int im_rstart(int row) { return SBM_IM_RSTART[IM_TRI ? row : 0]; }",
         "  __device__ __forceinline__ static int im_diagslot(int row) { return SBM_IM_DIAGSLOT[IM_TRI ? row : 0]; }",

@@ -45,6 +45,12 @@ from __future__ import annotations
 
 REG_ELEMS = 15      # elements per lane up to which DOPRI45's stage vectors fit 256 registers (two waves per SIMD)
 AGPR_ELEMS = 26     # ... up to which they fit 512 together with the operands (one wave per SIMD, v_accvgpr traffic); beyond: scratch
+# DOP853 keeps twelve vectors of a lane's elements alive where DOPRI45 keeps seven: its split (layout RG2) is planned with
+# budgets scaled by 7/12.  Measured on cascade20, 4096 vectors (scripts/dev_dop853.py): 14 elements per lane (the DOPRI45
+# split) 512 registers + 1078 scratch instructions, ~60 ms per pass; 7 elements in two column chunks 262 registers, no
+# scratch, ~3 ms.
+REG_ELEMS_853 = 8
+AGPR_ELEMS_853 = 15
 MAX_ROWS_PER_LANE = 4
 STATE_COST = 5      # work of the per-chunk state evaluation, in elements per lane
 
@@ -72,13 +78,13 @@ def _best_split(n, ncols, g_min, max_lanes=64):
 #       model cost                           75                76                 96                  120
 #   cascade20, 4096 vectors   (3,20,2,7,1)   5.05  (3,20,1,7,2)   6.66  (6,10,1,4,4)  8.85
 #       model cost                           19                24                 36
-def _cost(elems, nch, rpl=1):
+def _cost(elems, nch, rpl=1, reg_elems=REG_ELEMS, agpr_elems=AGPR_ELEMS):
     # the kernel runs two wavefronts per SIMD when elements + state rows per lane <= REG_ELEMS (SBM_RG_MIN_WAVES)
-    spill = 1.0 if elems + rpl <= REG_ELEMS else (1.6 if elems <= AGPR_ELEMS else 4.0 * elems / AGPR_ELEMS)
+    spill = 1.0 if elems + rpl <= reg_elems else (1.6 if elems <= agpr_elems else 4.0 * elems / agpr_elems)
     return nch * (elems + STATE_COST * rpl) * spill
 
 
-def plan(n, nk, max_lanes=64):
+def plan(n, nk, max_lanes=64, reg_elems=REG_ELEMS, agpr_elems=AGPR_ELEMS):
     """(G, C, CPL, RPG, NCH): lanes (g, c') of NCH column chunks.  None when the row-lane kernel does as
     well (one chunk, and splitting the rows cuts the elements per lane by less than 20 %) or the model has
     more than 4 x 64 state variables."""
@@ -86,7 +92,7 @@ def plan(n, nk, max_lanes=64):
         return None
     import os
     forced = os.environ.get('SBM_RG_FORCE_PLAN')        # developer aid: "G,C,CPL,RPG,NCH" (timing one split against another)
-    if forced:
+    if forced and reg_elems == REG_ELEMS:
         G, C, CPL, RPG, NCH = (int(v) for v in forced.split(','))
         assert G * C <= max_lanes and G * RPG >= n and C * CPL * NCH >= nk and C * CPL * (NCH - 1) < nk, forced
         return (G, C, CPL, RPG, NCH)
@@ -101,13 +107,13 @@ def plan(n, nk, max_lanes=64):
         sp = _best_split(n, ncols, 2 if nch == 1 else 1, max_lanes)
         if sp is None:
             continue
-        key = (_cost(sp[0], nch, rpl), nch)
+        key = (_cost(sp[0], nch, rpl, reg_elems, agpr_elems), nch)
         if best is None or key < best[0]:
             best = (key, sp, nch)
     if best is None:
         return None
     (_, sp, nch) = best
-    if nch == 1 and nk <= max_lanes and sp[0] > 0.8 * n:
+    if nch == 1 and nk <= max_lanes and sp[0] > 0.8 * n and reg_elems == REG_ELEMS:
         return None
     return sp[1:] + (nch,)
 
@@ -158,11 +164,22 @@ def latency_plan_or_none(n, nk):
     return p1
 
 
-def layout(spec, d, latency=False):
-    """Term structure of the row-group form (``latency``: the small-batch split).  Returns None when the form does
-    not apply (``latency``: or when the throughput split serves small batches as well)."""
+def dop853_plan_or_none(n, nk):
+    """The split for DOP853's twelve stage vectors, when the form applies at all and the split differs from the
+    throughput one; None: DOP853 runs the throughput split (small shares already)."""
+    p0 = plan(n, nk)
+    if p0 is None:
+        return None
+    p2 = plan(n, nk, reg_elems=REG_ELEMS_853, agpr_elems=AGPR_ELEMS_853)
+    return None if (p2 is None or p2 == p0) else p2
+
+
+def layout(spec, d, latency=False, dop853=False):
+    """Term structure of the row-group form (``latency``: the small-batch split; ``dop853``: the split planned for
+    twelve stage vectors).  Returns None when the form does not apply (``latency`` / ``dop853``: or when the throughput
+    split serves as well)."""
     n, nk = spec.n_vars, spec.n_sens
-    p = latency_plan_or_none(n, nk) if latency else plan(n, nk)
+    p = dop853_plan_or_none(n, nk) if dop853 else (latency_plan_or_none(n, nk) if latency else plan(n, nk))
     if p is None:
         return None
     G, C, CPL, RPG, NCH = p
@@ -211,9 +228,9 @@ def layout(spec, d, latency=False):
                 publish=sorted(publish), jys=jys, jypos=jypos, max_jy=max_jy, n_pad=n_pad)
 
 
-def emit_tables(spec, d, tag='RG0', latency=False):
-    """Namespace-scope tables of one layout (``tag``: RG0 = throughput split, RG1 = small-batch split)."""
-    lay = layout(spec, d, latency=latency)
+def emit_tables(spec, d, tag='RG0', latency=False, dop853=False):
+    """Namespace-scope tables of one layout (``tag``: RG0 = throughput split, RG1 = small-batch split, RG2 = DOP853's)."""
+    lay = layout(spec, d, latency=latency, dop853=dop853)
     if lay is None:
         return [], None
     n = spec.n_vars
@@ -232,7 +249,7 @@ def emit_members(spec, d, lay, tag='RG0', alias_of=None):
     over it); with ``lay is None`` only RG_OK = false and inert stubs -- or, with ``alias_of``, another name for
     that layout."""
     if lay is None and alias_of is not None:
-        return ["  using %s = %s;   // small batches run the throughput split" % (tag, alias_of)]
+        return ["  using %s = %s;   // this use runs the throughput split" % (tag, alias_of)]
     body = _emit_struct_body(spec, d, lay, tag)
     return ["  struct %s {" % tag] + body + ["  };"]
 
