@@ -288,6 +288,19 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
                                   "cost_median": float(np.median(fit_m['cost'])), "cost_max": float(np.max(fit_m['cost'])),
                                   "converged": int(fit_m['converged'].sum()),
                                   "note": "sbm_lm_step + lambda multiplied up / down by trial integrations (round 1)"}
+    # the same fit with the trajectories integrated by DOP853 (method='dop853': a seventh of the steps at these tolerances)
+    try:
+        proj.fit_batch(starts[:8], max_iter=3, method='dop853')
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        fit_8 = proj.fit_batch(starts, max_iter=100, ftol=1.49012e-8, xtol=1.49012e-8, method='dop853')
+        torch.cuda.synchronize(dev)
+        dt8 = time.perf_counter() - t0
+        out["integrated_with_dop853"] = {"seconds": dt8, "fits_per_s": n_starts / dt8, "cost_min": float(np.min(fit_8['cost'])),
+                                         "cost_median": float(np.median(fit_8['cost'])), "cost_max": float(np.max(fit_8['cost'])),
+                                         "converged": int(fit_8['converged'].sum())}
+    except Exception as e:   # noqa: BLE001
+        out["integrated_with_dop853"] = {"error": repr(e)[:200]}
     if cpu:
         from scipy.optimize import leastsq
         from oracle.project_oracle import ProjectOracle
