@@ -274,7 +274,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help="headline only: no other configs, no variants")
     ap.add_argument('--only', default=None, help="run one workload's GPU part alone, --steps times (profiling aid; "
-                    "headline, configs1, configs3, configs4, fit, dense); no JSON contract")
+                    "headline, configs1, configs3, configs4, fit, dense, dop853); no JSON contract")
     ap.add_argument('--cpu-baseline-only', action='store_true', help="time the CPU oracle and exit (no GPU needed)")
     args = ap.parse_args()
 

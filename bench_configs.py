@@ -471,5 +471,28 @@ def run_dense(model, gm, dev, reps=3, cpu=True):
     return out
 
 
-RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'fit': run_fit, 'dense': run_dense}
+def run_dop853(model, gm, dev, reps=3, cpu=True):
+    """The headline ensemble (4096 vectors, 820 ODEs, 16 output times) through the DOP853 kernel alone, at OdeModel's
+    default tolerances as the Python classes hand them to this method (rtol cut by ten): a profiling workload
+    (`bench.py --only dop853`); the full run reports it under extras."""
+    import torch
+    from sysbio_modeling_amd import _lib, models_zoo
+    V = 4096
+    _, P = models_zoo.cascade_ensemble(V)
+    dm = model.device_model
+    Pd = torch.from_numpy(P).to(dev)
+    grid = np.linspace(0, models_zoo.CASCADE_T_END, 1000)
+    tg = torch.from_numpy(np.concatenate([[0.0], grid[np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)]])).to(dev)
+    Yk = torch.empty((V, len(tg), 20), dtype=torch.float64, device=dev)
+    Sk = torch.empty((V, len(tg), 20, 40), dtype=torch.float64, device=dev)
+    ns = torch.empty((V,), dtype=torch.int32, device=dev)
+    o = _lib.make_opts('dop853', rtol=0.1 * model.integrator_options['rtol'], atol=model.integrator_options['atol'])
+    ms = _events(torch, dev, lambda: dm.sens_dev(Pd, tg, None, o, Yk, Sk, None, ns, None), reps)
+    steps = int(ns.sum().item())
+    return {"workload": "headline ensemble through DOP853 (kernel alone)", "ms": ms, "steps": steps,
+            "steps_per_s": steps / (ms * 1e-3), "algorithmic_GBps": steps * B.BYTES_PER_STEP / (ms * 1e-3) / 1e9}
+
+
+RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'fit': run_fit, 'dense': run_dense,
+           'dop853': run_dop853}
 ORDER = ['configs1', 'configs3', 'configs4', 'fit', 'dense']

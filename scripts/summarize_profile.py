@@ -31,6 +31,7 @@ KEYS = {
     'imid_stiff50': ('configs4', r'sbm_imid', ('configs4', 'steps'), None),
     'lm_step': ('fit', r'k_lm_step', None, None),
     'assemble': ('headline', r'k_assemble', None, 1),
+    'sens_rowgroup_cascade20_dop853': ('dop853', r'sbm_sens_rowgroup_kernel<.*RG2, 5>', ('dop853', 'steps'), 1),
     'dense20_valu': ('dense', r'sbm_sens_rowlane_kernel', ('dense', 'valu', 'steps'), 1),
     'dense20_mfma': ('dense', r'sbm_sens_mfma_kernel', ('dense', 'mfma', 'steps'), 1),
 }
