@@ -9,16 +9,20 @@ from sysbio_modeling_amd.symbolic import zoo_model
 gm = zoo_model('cascade20')
 m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order)
 proj, th = models_zoo.cascade_config4_project(m)
-for name, fn in (('residuals', lambda: proj.residuals(th)), ('calc_project_jacobian', lambda: proj.calc_project_jacobian(th)),
-                 ('calc_rss_gradient', lambda: proj.calc_rss_gradient(th)),
-                 ('OdeModel.simulate', lambda: m.simulate(models_zoo.cascade_nominal_params(), np.linspace(0, 100, 1000))),
-                 ('OdeModel.calc_jacobian', lambda: m.calc_jacobian(models_zoo.cascade_nominal_params(), np.linspace(0, 100, 1000), np.zeros(820)))):
-    fn()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        fn()
-    print("%-24s %.2f ms per call" % (name, (time.perf_counter() - t0) / 20 * 1e3))
+for method in ('dopri45', 'dop853'):
+  m.integrator_options['method'] = method
+  print('--- model option method =', method)
+  for name, fn in (('residuals', lambda: proj.residuals(th)), ('calc_project_jacobian', lambda: proj.calc_project_jacobian(th)),
+                   ('calc_rss_gradient', lambda: proj.calc_rss_gradient(th)),
+                   ('OdeModel.simulate', lambda: m.simulate(models_zoo.cascade_nominal_params(), np.linspace(0, 100, 1000))),
+                   ('OdeModel.calc_jacobian', lambda: m.calc_jacobian(models_zoo.cascade_nominal_params(), np.linspace(0, 100, 1000), np.zeros(820)))):
+      fn()
+      t0 = time.perf_counter()
+      for _ in range(20):
+          fn()
+      print("%-24s %.2f ms per call" % (name, (time.perf_counter() - t0) / 20 * 1e3))
 
+m.integrator_options['method'] = 'dopri45'
 # where the time of one residuals() call goes: kernel time by events around the C call alone
 import torch
 from sysbio_modeling_amd import _lib

@@ -654,9 +654,11 @@ class Project(object):
                                                      set(integrator_overrides) | set(self.integrator_options))
                 oi['max_steps'] = 0          # the budget belongs to the explicit attempt; the kernel's own limit here
                 return split(self._evaluate_once(t, jacobian, want, extrapolate=0, **oi, **keep)) + (None,)
+            explicit_method = str(o.get('explicit_method', 'dopri45'))       # 'dop853': the eighth-order pair for the attempt
+            ex_tol = _lib.implicit_adaptive_defaults(dict(method=explicit_method, rtol=rtol, atol=atol),
+                                                     set(integrator_overrides) | set(self.integrator_options))
             out, st, steps, stiff = _control.with_stiff_fallback(
-                lambda: split(self._evaluate_once(th, jacobian, want, method='dopri45', max_steps=-budget,
-                                                  rtol=rtol, atol=atol, extrapolate=0, **keep)),
+                lambda: split(self._evaluate_once(th, jacobian, want, max_steps=-budget, extrapolate=0, **ex_tol, **keep)),
                 implicit if self._model.n_vars <= _lib.IMPLICIT_MAX_NV else None, V)
         out['status'] = torch.as_tensor(st, dtype=torch.int32, device=th.device)
         out['n_steps'] = torch.as_tensor(np.minimum(steps, 2 ** 31 - 1), dtype=torch.int32, device=th.device)

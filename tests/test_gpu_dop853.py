@@ -155,3 +155,27 @@ def test_project_rows_with_dop853(gpu_models, zoo):
         assert tol_ratio(res_only['residuals'][v], rr, t['residuals']) <= 1.0
     fit = proj.fit_batch(thetas, max_iter=5, method='dop853')
     assert np.all(fit['cost'] <= 0.5 * out['norms'] + 1e-12)
+
+
+def test_single_vector_methods_keep_the_stiff_fallback(gpu_models, golden):
+    """A model whose options name 'dop853' keeps what the single-vector methods do by default: method='auto', with the
+    eighth-order pair as the explicit attempt -- a stiff vector (the stiff50 golden) still reaches the implicit
+    integrator, a mild one carries the numbers of a plain DOP853 call."""
+    from sysbio_modeling_amd.model import OdeModel
+    from sysbio_modeling_amd.symbolic import zoo_model
+    gm = zoo_model('stiff50')
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name='stiff50')
+    m.integrator_options['method'] = 'dop853'
+    g = golden('stiff50_ref.npz')
+    y = m.simulate(g['P'][0], g['t'])
+    assert m.last_info['stiff'].tolist() == [True]
+    assert parity_err(y[g['idx']], g['Y'][0]) <= 1.0
+    mild = g['P'][0].copy()
+    mild[:50] = 10.0 ** np.linspace(0.0, 1.0, 50)
+    t_out = _from_zero(g['t'][g['idx']])
+    y1 = m.simulate(mild, t_out)
+    assert m.last_info['stiff'].tolist() == [False]
+    assert np.array_equal(y1, m.simulate_batch(mild[None, :], t_out)[0])
+    # and a batch call with the method spelled out: 'auto' with explicit_method
+    Y2 = m.simulate_batch(np.stack([g['P'][0], mild]), t_out, method='auto', explicit_method='dop853', max_steps=20000)
+    assert m.last_info['stiff'].tolist() == [True, False] and np.array_equal(Y2[1], y1)
