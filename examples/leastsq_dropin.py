@@ -64,6 +64,17 @@ def main():
         dt = time.time() - t0
         print("far start, %-31s %3d + %3d calls in %5.2f s, cost %.3f" % (label + ':', calls['f'], calls['J'], dt,
                                                                            0.5 * np.sum(info['fvec'] ** 2)))
+    # The same serial fit with the eighth-order explicit pair: a seventh of the sequential steps per call.  The model's
+    # option names it; the single-vector methods keep their stiff fallback (method='auto', explicit_method='dop853').
+    proj.integrator_options.clear()
+    model.integrator_options['method'] = 'dop853'
+    f(x0), J(x0)
+    calls.update(f=0, J=0)
+    t0 = time.time()
+    x, cov, info, msg, ier = scipy.optimize.leastsq(f, x0, Dfun=J, full_output=True, maxfev=400)
+    dt = time.time() - t0
+    print("model option method='dop853': %d residual calls + %d Jacobian calls in %.2f s (%.2f ms per call), cost %.3f"
+          % (calls['f'], calls['J'], dt, 1e3 * dt / max(calls['f'] + calls['J'], 1), 0.5 * np.sum(info['fvec'] ** 2)))
 
 
 if __name__ == '__main__':
