@@ -575,30 +575,55 @@ __device__ __forceinline__ SbmTrajOut sbm_dop853(const Sys& sys, double (&z)[Sys
       bool last = false;
       if (t + 1.01 * hs >= target) { hs = target - t; last = true; }
 
-      // the step size multiplies each finished sum once (tableau entries stay literals, as in sbm_dopri45)
-      SBM_STAGE(t + C2 * hs, zt[c][i] = fma(hs * A2_1, k1[c][i], z[c][i]);, kx)                                  // k2
-      SBM_STAGE(t + C3 * hs, zt[c][i] = fma(hs, fma(A3_2, kx[c][i], A3_1 * k1[c][i]), z[c][i]);, ky)              // k3
-      SBM_STAGE(t + C4 * hs, zt[c][i] = fma(hs, fma(A4_3, ky[c][i], A4_1 * k1[c][i]), z[c][i]);, kx)              // k4
-      SBM_STAGE(t + C5 * hs, zt[c][i] = fma(hs, fma(A5_4, kx[c][i], fma(A5_3, ky[c][i], A5_1 * k1[c][i])), z[c][i]);, k5)
-      SBM_STAGE(t + C6 * hs, zt[c][i] = fma(hs, fma(A6_5, k5[c][i], fma(A6_4, kx[c][i], A6_1 * k1[c][i])), z[c][i]);, ky)   // k6
-      SBM_STAGE(t + C7 * hs,
-                zt[c][i] = fma(hs, fma(A7_6, ky[c][i], fma(A7_5, k5[c][i], fma(A7_4, kx[c][i], A7_1 * k1[c][i]))), z[c][i]);, k7)
-      SBM_STAGE(t + C8 * hs,
-                zt[c][i] = fma(hs, fma(A8_7, k7[c][i], fma(A8_6, ky[c][i], fma(A8_5, k5[c][i], fma(A8_4, kx[c][i],
-                               A8_1 * k1[c][i])))), z[c][i]);, k8)
-      SBM_STAGE(t + C9 * hs,
-                zt[c][i] = fma(hs, fma(A9_8, k8[c][i], fma(A9_7, k7[c][i], fma(A9_6, ky[c][i], fma(A9_5, k5[c][i],
-                               fma(A9_4, kx[c][i], A9_1 * k1[c][i]))))), z[c][i]);, k9)
-      SBM_STAGE(t + C10 * hs,
-                zt[c][i] = fma(hs, fma(A10_9, k9[c][i], fma(A10_8, k8[c][i], fma(A10_7, k7[c][i], fma(A10_6, ky[c][i],
-                               fma(A10_5, k5[c][i], fma(A10_4, kx[c][i], A10_1 * k1[c][i])))))), z[c][i]);, k10)
-      SBM_STAGE(t + C11 * hs,
-                zt[c][i] = fma(hs, fma(A11_10, k10[c][i], fma(A11_9, k9[c][i], fma(A11_8, k8[c][i], fma(A11_7, k7[c][i],
-                               fma(A11_6, ky[c][i], fma(A11_5, k5[c][i], fma(A11_4, kx[c][i], A11_1 * k1[c][i]))))))), z[c][i]);, k11)
-      SBM_STAGE(t + hs,
-                zt[c][i] = fma(hs, fma(A12_11, k11[c][i], fma(A12_10, k10[c][i], fma(A12_9, k9[c][i], fma(A12_8, k8[c][i],
-                               fma(A12_7, k7[c][i], fma(A12_6, ky[c][i], fma(A12_5, k5[c][i], fma(A12_4, kx[c][i],
-                               A12_1 * k1[c][i])))))))), z[c][i]);, k12)
+      // The step size multiplies each finished sum once (tableau entries stay literals, as in sbm_dopri45).  Stages are
+      // software-pipelined as there: stage s+1's state path (extra elements, LDS hand-off, operand fetch) is issued
+      // between the row evaluation and the column work of stage s.
+      const double ha21 = hs * A2_1;
+#define SBM_D2 zt[c][i] = fma(ha21, k1[c][i], z[c][i]);
+#define SBM_D3 zt[c][i] = fma(hs, fma(A3_2, kx[c][i], A3_1 * k1[c][i]), z[c][i]);
+#define SBM_D4 zt[c][i] = fma(hs, fma(A4_3, ky[c][i], A4_1 * k1[c][i]), z[c][i]);
+#define SBM_D5 zt[c][i] = fma(hs, fma(A5_4, kx[c][i], fma(A5_3, ky[c][i], A5_1 * k1[c][i])), z[c][i]);
+#define SBM_D6 zt[c][i] = fma(hs, fma(A6_5, k5[c][i], fma(A6_4, kx[c][i], A6_1 * k1[c][i])), z[c][i]);
+#define SBM_D7 zt[c][i] = fma(hs, fma(A7_6, ky[c][i], fma(A7_5, k5[c][i], fma(A7_4, kx[c][i], A7_1 * k1[c][i]))), z[c][i]);
+#define SBM_D8                                                                                                      \
+  zt[c][i] = fma(hs, fma(A8_7, k7[c][i], fma(A8_6, ky[c][i], fma(A8_5, k5[c][i], fma(A8_4, kx[c][i], A8_1 * k1[c][i])))), \
+                 z[c][i]);
+#define SBM_D9                                                                                                      \
+  zt[c][i] = fma(hs, fma(A9_8, k8[c][i], fma(A9_7, k7[c][i], fma(A9_6, ky[c][i], fma(A9_5, k5[c][i],                 \
+                 fma(A9_4, kx[c][i], A9_1 * k1[c][i]))))), z[c][i]);
+#define SBM_D10                                                                                                     \
+  zt[c][i] = fma(hs, fma(A10_9, k9[c][i], fma(A10_8, k8[c][i], fma(A10_7, k7[c][i], fma(A10_6, ky[c][i],             \
+                 fma(A10_5, k5[c][i], fma(A10_4, kx[c][i], A10_1 * k1[c][i])))))), z[c][i]);
+#define SBM_D11                                                                                                     \
+  zt[c][i] = fma(hs, fma(A11_10, k10[c][i], fma(A11_9, k9[c][i], fma(A11_8, k8[c][i], fma(A11_7, k7[c][i],           \
+                 fma(A11_6, ky[c][i], fma(A11_5, k5[c][i], fma(A11_4, kx[c][i], A11_1 * k1[c][i]))))))), z[c][i]);
+#define SBM_D12                                                                                                     \
+  zt[c][i] = fma(hs, fma(A12_11, k11[c][i], fma(A12_10, k10[c][i], fma(A12_9, k9[c][i], fma(A12_8, k8[c][i],         \
+                 fma(A12_7, k7[c][i], fma(A12_6, ky[c][i], fma(A12_5, k5[c][i], fma(A12_4, kx[c][i],                 \
+                 A12_1 * k1[c][i])))))))), z[c][i]);
+      SBM_ISSUE(t + C2 * hs, SBM_D2)
+      SBM_STAGE_THEN(t + C2 * hs, SBM_D2, kx, SBM_ISSUE(t + C3 * hs, SBM_D3))       // k2
+      SBM_STAGE_THEN(t + C3 * hs, SBM_D3, ky, SBM_ISSUE(t + C4 * hs, SBM_D4))       // k3
+      SBM_STAGE_THEN(t + C4 * hs, SBM_D4, kx, SBM_ISSUE(t + C5 * hs, SBM_D5))       // k4 takes k2's storage
+      SBM_STAGE_THEN(t + C5 * hs, SBM_D5, k5, SBM_ISSUE(t + C6 * hs, SBM_D6))
+      SBM_STAGE_THEN(t + C6 * hs, SBM_D6, ky, SBM_ISSUE(t + C7 * hs, SBM_D7))       // k6 takes k3's storage
+      SBM_STAGE_THEN(t + C7 * hs, SBM_D7, k7, SBM_ISSUE(t + C8 * hs, SBM_D8))
+      SBM_STAGE_THEN(t + C8 * hs, SBM_D8, k8, SBM_ISSUE(t + C9 * hs, SBM_D9))
+      SBM_STAGE_THEN(t + C9 * hs, SBM_D9, k9, SBM_ISSUE(t + C10 * hs, SBM_D10))
+      SBM_STAGE_THEN(t + C10 * hs, SBM_D10, k10, SBM_ISSUE(t + C11 * hs, SBM_D11))
+      SBM_STAGE_THEN(t + C11 * hs, SBM_D11, k11, SBM_ISSUE(t + hs, SBM_D12))
+      SBM_STAGE_THEN(t + hs, SBM_D12, k12, )
+#undef SBM_D2
+#undef SBM_D3
+#undef SBM_D4
+#undef SBM_D5
+#undef SBM_D6
+#undef SBM_D7
+#undef SBM_D8
+#undef SBM_D9
+#undef SBM_D10
+#undef SBM_D11
+#undef SBM_D12
 
       // 8th-order solution into zt; the two error estimates, ratios and norms in f32 (they only steer the controller)
       float cs5[Sys::NCS], cs3[Sys::NCS];
