@@ -37,6 +37,11 @@ MORE THAN 64 STATE VARIABLES.  The state lives one component per lane; beyond 64
 lane, lane + 64, ... (up to four), evaluating their classes one after the other.  Nothing else changes:
 the tables are indexed by global row.
 
+THREE LAYOUTS of the same form are emitted per model, nested structs the kernels are templates over: RG0 (the
+throughput split, planned for DOPRI45's seven stage vectors), RG1 (small batches: more, smaller column chunks -- a single
+parameter vector leaves the chip empty and extra wavefronts are free), RG2 (DOP853: twelve stage vectors, the planner's
+register budgets scaled by 7/12).  RG1 / RG2 are aliases of RG0 where the planner finds nothing different.
+
 ``plan`` decides whether the form pays at all (RG_OK); the integrator falls back to the
 row-lane kernel (or, beyond 64 columns, to the per-wave kernel) otherwise.
 """
