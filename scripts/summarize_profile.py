@@ -30,6 +30,7 @@ KEYS = {
     'state_packed_cascade20_rk4_fixed_4096': ('configs1', r'sbm_state_packed_kernel<.*, 0, ', ('configs1', 'rk4_fixed_4096', 'steps'), 1),
     'imid_stiff50': ('configs4', r'sbm_imid', ('configs4', 'steps'), None),
     'lm_step': ('fit', r'k_lm_step', None, None),
+    'lm_trust_step': ('fit', r'k_lm_trust', None, None),
     'assemble': ('headline', r'k_assemble', None, 1),
     'sens_rowgroup_cascade20_dop853': ('dop853', r'sbm_sens_rowgroup_kernel<.*RG2, 5>', ('dop853', 'steps'), 1),
     'dense20_valu': ('dense', r'sbm_sens_rowlane_kernel', ('dense', 'valu', 'steps'), 1),
