@@ -34,7 +34,9 @@ print('gradient norm at the end', np.linalg.norm(g), 'cost', 0.5 * r @ r, 'singu
 import time
 import torch
 starts256 = th0[None, :] + 0.15 * np.random.default_rng(1).standard_normal((256, th0.size))
-for label, kw in (('marquardt', dict(algorithm='marquardt')),
+for label, kw in (('trust_region, budget 2000', dict(algorithm='trust_region', max_steps=-2000)),
+                  ('trust_region, budget 3000', dict(algorithm='trust_region', max_steps=-3000)),
+                  ('marquardt', dict(algorithm='marquardt')),
                   ('trust_region, clip 2, factor 100', dict(algorithm='trust_region')),
                   ('trust_region, clip 20, factor 100', dict(algorithm='trust_region', max_step=20.0)),
                   ('trust_region, clip 2, factor 1', dict(algorithm='trust_region', factor=1.0)),
