@@ -29,22 +29,38 @@ from . import emit_implicit
 _RCP = sympy.Function('SBM_RCP')
 
 
+_cheapest_memo = {}
+
+
 def _cheapest(expr):
     """Derivatives of rational rate laws come out of ``diff`` as sums such as
     k/(1+x) - k*x/(1+x)**2; the factored form k/(1+x)**2 is a third of the work.
-    Pick the cheapest of raw / factored / simplified (divisions weighted heavily)."""
+    Pick the cheapest of raw / factored / simplified (divisions weighted heavily).
+
+    Networks repeat a few kinetic forms over many species, so the same expression comes back with other symbols
+    hundreds of times (the dense 20-state network: 440 Jacobian entries, 3.5 minutes of ``simplify``): the work is done
+    once per STRUCTURE -- symbols renamed to placeholders in order of first appearance -- and renamed back."""
     def cost(e):
         return sympy.count_ops(e, visual=False) + 8 * len([a for a in sympy.preorder_traversal(e)
                                                            if a.is_Pow and a.exp.is_number and a.exp.is_negative])
-    best = expr
-    for f in (sympy.factor, sympy.simplify):
-        try:
-            cand = f(expr)
-        except Exception:
-            continue
-        if cost(cand) < cost(best):
-            best = cand
-    return best
+    order = []
+    for node in sympy.preorder_traversal(expr):
+        if isinstance(node, Symbol) and node not in order:
+            order.append(node)
+    fwd = {sym: Symbol('_q%d' % i) for i, sym in enumerate(order)}
+    canon = expr.xreplace(fwd)
+    key = sympy.srepr(canon)
+    if key not in _cheapest_memo:
+        best = canon
+        for f in (sympy.factor, sympy.simplify):
+            try:
+                cand = f(canon)
+            except Exception:
+                continue
+            if cost(cand) < cost(best):
+                best = cand
+        _cheapest_memo[key] = best
+    return _cheapest_memo[key].xreplace({v: k for k, v in fwd.items()})
 
 
 def _canon_rcp(expr):
