@@ -61,7 +61,7 @@ class GeneratedModel(object):
         self._c_lib = None
 
     # -- derivation cache -------------------------------------------------------------------------------------
-    # Deriving and printing a large model costs minutes of SymPy (a densely coupled 20-state network: 3.5 min);
+    # Deriving and printing a large model costs SymPy time (seconds to a minute for models of this size);
     # the three generated texts are kept under _build/gen/, keyed by the model's equations and the emitters' own
     # sources, so that a second process (a test, the benchmark, a rank of a multi-GPU job) starts in milliseconds.
     @property
