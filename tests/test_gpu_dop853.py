@@ -179,3 +179,45 @@ def test_single_vector_methods_keep_the_stiff_fallback(gpu_models, golden):
     # and a batch call with the method spelled out: 'auto' with explicit_method
     Y2 = m.simulate_batch(np.stack([g['P'][0], mild]), t_out, method='auto', explicit_method='dop853', max_steps=20000)
     assert m.last_info['stiff'].tolist() == [True, False] and np.array_equal(Y2[1], y1)
+
+
+def _lsoda_worker(args):
+    P, grid, idx = args
+    from oracle import odeint_oracle as oo
+    from sysbio_modeling_amd.symbolic import zoo_model
+    gm = zoo_model('cascade20')
+    out = []
+    for p in P:
+        S, Y = oo.calc_jacobian(gm, p, grid, use_c=True, return_states=True)
+        out.append(np.concatenate([Y[idx], S[idx]], axis=1))
+    return out
+
+
+def test_headline_ensemble_256_vectors_against_the_oracle(gpu_models, zoo):
+    """256 vectors spread over the headline ensemble, every sampled state and sensitivity against the oracle's LSODA call
+    (as tests/test_gpu_parity_sweeps.py does for DOPRI45 on 1024): where a vector exceeds the parity tolerance the
+    disagreement must be LSODA's own error, shown against a tight solution."""
+    from oracle import odeint_oracle as oo
+    from sysbio_modeling_amd import models_zoo
+    gm = zoo('cascade20')
+    gm.c_library()
+    m = gpu_models('cascade20')
+    _, P = models_zoo.cascade_ensemble(4096)
+    pick = np.arange(0, 4096, 16)
+    grid = np.linspace(0, 100.0, 1000)
+    idx = np.searchsorted(grid, models_zoo.CASCADE_MEASURE_TIMES)
+    t_out = _from_zero(grid[idx])
+    S, Y = m.calc_jacobian_batch(P[pick], t_out, return_states=True, method='dop853')
+    assert not m.last_info['status'].any()
+    chunks = np.array_split(np.arange(len(pick)), 12)
+    with mp.get_context('spawn').Pool(12) as pool:
+        ref = [x for part in pool.map(_lsoda_worker, [(P[pick[c]], grid, idx) for c in chunks]) for x in part]
+    got = np.concatenate([Y[:, 1:], S[:, 1:]], axis=2)
+    err = np.array([parity_err(got[v], ref[v]) for v in range(len(pick))])
+    over = np.flatnonzero(err > 1.0)
+    for v in over:
+        tight = oo.tight_solution(gm, P[pick[v]], t_out, use_c=True, atol=1e-30)[1:]
+        check_parity(got[v], ref[v], tight, what='vector %d' % pick[v])
+    assert len(over) <= 8
+    print("DOP853, 256 vectors: error against LSODA median %.3f p99 %.3f max %.3f parity units; %d beyond 1 (LSODA's own error)"
+          % (np.median(err), np.percentile(err, 99), err.max(), len(over)))
