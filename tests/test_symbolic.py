@@ -371,3 +371,24 @@ def test_symbolic_lu_fill_in():
     # lower bidiagonal: no fill
     pattern, ops = symbolic_lu(n, [(i, i - 1) for i in range(1, n)] + [(i, i) for i in range(n)])
     assert len(pattern) == 2 * n - 1 and all(j <= i for i, j in pattern)
+
+
+def test_simplification_is_done_once_per_structure_and_renamed_back():
+    """emit._cheapest works on a placeholder form of the expression and renames the result: the same kinetic form with
+    other symbols gives the same result up to that renaming, equal in value to the input, and costs one dictionary
+    look-up the second time."""
+    from sysbio_modeling_amd.symbolic import emit
+    a, b, x, y = sympy.symbols('a b x y')
+    k, K, u, v = sympy.symbols('k K u v')
+    e1 = sympy.diff(a * x / (b + x) - y * x, x)
+    e2 = sympy.diff(k * u / (K + u) - v * u, u)
+    emit._cheapest_memo.clear()
+    r1 = emit._cheapest(e1)
+    n_after_first = len(emit._cheapest_memo)
+    r2 = emit._cheapest(e2)
+    assert len(emit._cheapest_memo) == n_after_first == 1
+    assert sympy.simplify(r1 - e1) == 0 and sympy.simplify(r2 - e2) == 0
+    assert r1.xreplace({a: k, b: K, x: u, y: v}) == r2
+    assert sympy.count_ops(r1) <= sympy.count_ops(e1)
+    # no placeholder leaks into the result
+    assert r1.free_symbols <= {a, b, x, y} and r2.free_symbols <= {k, K, u, v}
