@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SBM_ABI_VERSION 3   /* 3: + sbm_lm_trust_step */
+#define SBM_ABI_VERSION 4   /* 3: + sbm_lm_trust_step; 4: + SBM_IMPLICIT_EXTRAP */
 
 typedef struct sbm_ctx sbm_ctx;
 typedef struct sbm_model sbm_model;
@@ -72,11 +72,22 @@ enum {
    * DOPRI45's steps and a third of its right-hand-side evaluations on the 20-state model with sensitivities.  Runs on
    * the row-group sensitivity kernels and the state-rows / packed state kernels (models whose rows the generator could
    * split: sbm_model_info; others answer SBM_E_ARG).  opts.variant: AUTO or SMALL_BATCH. */
-  SBM_DOP853 = 5
+  SBM_DOP853 = 5,
+  /* Stiff systems with LOCAL error control, one call, no step count and no restarts: extrapolated implicit Euler.  A
+   * macro step of size H is integrated K times, with 1, 2, ..., K implicit-Euler steps (Newton with the model's
+   * symbolic sparse LU, sensitivities as the exact derivative of every Euler step: one solve per column with Newton's
+   * factors); polynomial extrapolation to step size zero gives a result of order K and an embedded one of order K - 1
+   * whose difference drives a per-trajectory step-size controller inside the kernel, as LSODA controls its own steps
+   * (model/ode_model.py:122-123,167-168).  L-stable: every sub-result damps stiff components, so does any combination.
+   * rtol / atol as for DOPRI45 (state AND sensitivities, column by column); h0 = first step (<= 0: automatic);
+   * step_mult = K (0: 4 / 6 / 8 by rtol; at most 10); max_steps counts macro steps.  n_steps = accepted macro steps
+   * (K (K + 1) / 2 Euler steps each), n_reject = rejected ones.  Needs n_vars <= SBM_IMPLICIT_MAX_NV.  What
+   * method='auto' of the Python classes switches to for vectors the explicit integrator gives up on (since ABI 4). */
+  SBM_IMPLICIT_EXTRAP = 6
 };
 
 typedef struct sbm_integrator_opts {
-  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_DOP853 | SBM_IMPLICIT_MIDPOINT[_GRADED] | SBM_IMPLICIT_ADAPTIVE */
+  int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_DOP853 | SBM_IMPLICIT_MIDPOINT[_GRADED] | SBM_IMPLICIT_ADAPTIVE | SBM_IMPLICIT_EXTRAP */
   int32_t max_steps; /* per trajectory, accepted + rejected; 0 -> 1000000.  DOPRI45, negative: a budget of
                       * (and DOP853) |max_steps| with an early exit (status SBM_MAX_STEPS at once) for a trajectory whose
                       * current step size would need more than four budgets for the remaining time span --

@@ -13,7 +13,7 @@ from . import build
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
-ABI_VERSION = 3      # include/sbm.h: SBM_ABI_VERSION
+ABI_VERSION = 4      # include/sbm.h: SBM_ABI_VERSION
 SBM_RK4_FIXED = 0
 SBM_DOPRI45 = 1
 SBM_DOP853 = 5
@@ -21,6 +21,7 @@ DOP853 = ('dop853', 'dopri853', 'dopri8')
 SBM_IMPLICIT_MIDPOINT = 2
 SBM_IMPLICIT_MIDPOINT_GRADED = 3
 SBM_IMPLICIT_ADAPTIVE = 4
+SBM_IMPLICIT_EXTRAP = 6
 IMPLICIT_MAX_NV = 128     # include/sbm.h: SBM_IMPLICIT_MAX_NV
 STATUS_NAMES = {0: 'ok', 1: 'max_steps', 2: 'non_finite', 3: 'step_underflow', 4: 'newton_fail',
                 5: 'tolerance_not_reached'}
@@ -141,7 +142,9 @@ def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-IMPLICIT_ADAPTIVE = ('implicit_adaptive', 'implicit', 'imid_adaptive', 'implicit_controlled', 'implicit_auto', 'stiff')
+IMPLICIT_ADAPTIVE = ('implicit_adaptive', 'imid_adaptive', 'implicit_controlled', 'implicit_auto')
+# extrapolated implicit Euler with local step-size control (csrc/sbm_implicit_extrap.hpp): THE stiff integrator since round 3
+IMPLICIT_EXTRAP = ('implicit_extrap', 'implicit', 'stiff', 'seulex', 'extrapolated_euler', 'implicit_euler_extrap')
 IMPLICIT_GRADED = ('implicit_midpoint_graded', 'imid_graded')
 FIXED_STEP_IMPLICIT = ('implicit_midpoint', 'imid', 'midpoint') + IMPLICIT_GRADED
 VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3, 'small_batch': 4, 'mfma': 5, 'packed': 6}
@@ -175,7 +178,7 @@ def implicit_adaptive_defaults(o, explicit):
 
 
 def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_steps=None, t_end=None, t0=0.0,
-              variant='auto', step_mult=0):
+              variant='auto', step_mult=0, order=0):
     """IntegratorOpts from keywords.  For the fixed-step methods ('rk4', 'implicit_midpoint') give h0 or
     (n_steps, t_end); rtol / atol are the Newton tolerances of 'implicit_midpoint'."""
     if isinstance(method, str):
@@ -186,6 +189,8 @@ def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_st
             m = SBM_DOP853
         elif key in ('rk4', 'rk4_fixed'):
             m = SBM_RK4_FIXED
+        elif key in IMPLICIT_EXTRAP:
+            m = SBM_IMPLICIT_EXTRAP
         elif key in IMPLICIT_ADAPTIVE:
             m = SBM_IMPLICIT_ADAPTIVE
         elif key in IMPLICIT_GRADED:
@@ -193,7 +198,7 @@ def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_st
         elif key in FIXED_STEP_IMPLICIT:
             m = SBM_IMPLICIT_MIDPOINT
         else:
-            raise ValueError("unknown integrator %r (use 'dopri45', 'dop853', 'rk4', 'implicit_adaptive', 'implicit_midpoint' or "
+            raise ValueError("unknown integrator %r (use 'dopri45', 'dop853', 'rk4', 'implicit_extrap', 'implicit_adaptive', 'implicit_midpoint' or "
                              "'implicit_midpoint_graded')" % method)
     else:
         m = int(method)
@@ -202,6 +207,8 @@ def make_opts(method='dopri45', rtol=1e-9, atol=1e-12, h0=0.0, max_steps=0, n_st
             raise ValueError("a fixed-step method needs h0, or n_steps together with t_end")
         h0 = (float(t_end) - float(t0)) / int(n_steps)
     v = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    if m == SBM_IMPLICIT_EXTRAP and order:
+        step_mult = int(order)        # the extrapolation order K travels in step_mult (include/sbm.h)
     return IntegratorOpts(m, int(max_steps), float(rtol), float(atol), float(h0), float(t0), v, int(step_mult))
 
 

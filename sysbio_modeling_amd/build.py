@@ -141,6 +141,7 @@ def build_plugin(name, header_path, force=False, extra_flags=()):
     out = plugin_path(name)
     srcs = [header_path, os.path.join(CSRC_DIR, 'sbm_plugin_main.hip'),
             os.path.join(CSRC_DIR, 'sbm_integrators.hpp'), os.path.join(CSRC_DIR, 'sbm_implicit_adaptive.hpp'),
+            os.path.join(CSRC_DIR, 'sbm_implicit_extrap.hpp'),
             os.path.join(CSRC_DIR, 'sbm_implicit_stepper.hpp'),
             os.path.join(CSRC_DIR, 'sbm_sens_mfma.hpp'),
             os.path.join(CSRC_DIR, 'sbm_plugin.h'),

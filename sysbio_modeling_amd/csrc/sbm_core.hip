@@ -203,7 +203,8 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
   if (!o) return sbm_fail(SBM_E_ARG, "%s: opts is NULL", who);
   if (o->method == SBM_RK4_FIXED) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: RK4 needs h0 > 0", who);
-  } else if (o->method == SBM_DOPRI45 || o->method == SBM_DOP853 || o->method == SBM_IMPLICIT_ADAPTIVE) {
+  } else if (o->method == SBM_DOPRI45 || o->method == SBM_DOP853 || o->method == SBM_IMPLICIT_ADAPTIVE ||
+             o->method == SBM_IMPLICIT_EXTRAP) {
     if (!(o->rtol > 0.0) || !(o->atol > 0.0)) return sbm_fail(SBM_E_ARG, "%s: adaptive methods need rtol, atol > 0", who);
   } else if (o->method == SBM_IMPLICIT_MIDPOINT || o->method == SBM_IMPLICIT_MIDPOINT_GRADED) {
     if (!(o->h0 > 0.0)) return sbm_fail(SBM_E_ARG, "%s: implicit midpoint needs h0 > 0", who);
@@ -217,8 +218,8 @@ static int check_opts(const sbm_integrator_opts* o, const char* who) {
 }
 
 static int check_model_fits(const sbm_model* m, const sbm_integrator_opts& o, const char* who) {
-  if ((o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED || o.method == SBM_IMPLICIT_ADAPTIVE) &&
-      m->info.n_vars > SBM_IMPLICIT_MAX_NV)
+  if ((o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED || o.method == SBM_IMPLICIT_ADAPTIVE ||
+       o.method == SBM_IMPLICIT_EXTRAP) && m->info.n_vars > SBM_IMPLICIT_MAX_NV)
     return sbm_fail(SBM_E_ARG, "%s: the implicit midpoint kernels hold a column of the sensitivity matrix per lane in "
                     "registers: n_vars <= %d (model '%s' has %d)", who, SBM_IMPLICIT_MAX_NV, m->info.name, m->info.n_vars);
   return 0;
@@ -226,7 +227,8 @@ static int check_model_fits(const sbm_model* m, const sbm_integrator_opts& o, co
 
 static int launch_failed(sbm_model* m, const sbm_integrator_opts& o, int e, const char* who) {
   if (e == (int)hipErrorInvalidConfiguration &&
-      (o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED || o.method == SBM_IMPLICIT_ADAPTIVE))
+      (o.method == SBM_IMPLICIT_MIDPOINT || o.method == SBM_IMPLICIT_MIDPOINT_GRADED || o.method == SBM_IMPLICIT_ADAPTIVE ||
+       o.method == SBM_IMPLICIT_EXTRAP))
     return sbm_fail(SBM_E_ARG, "%s: model '%s' (%d state variables, %d sensitivity columns) does not fit the implicit kernel "
                     "asked for: its tables need more than the 160 KB of LDS of a compute unit (the error-controlled kernel "
                     "parks two copies of a 64-column block of S there); the fixed-step method may still fit", who,

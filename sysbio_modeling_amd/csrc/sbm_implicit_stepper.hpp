@@ -275,4 +275,15 @@ struct SbmImplicitStepper {
 #pragma unroll
     for (int i = 0; i < NV; ++i) z[i] = fma(2.0, b[i], -z[i]);
   }
+
+  // one implicit-EULER step (hh = the step) of a sensitivity column with the matrices newton() left, in place:
+  // z <- M^-1 (z + hh J_p) -- the exact derivative of y_{n+1} = y_n + hh f(y_{n+1})  (sbm_implicit_extrap.hpp)
+  __device__ __forceinline__ void sens_euler(double hh, double (&z)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) z[i] = fma(hh, a_of(i), z[i]);
+    if constexpr (DIST) M::im_solve_lds(sh->MF, sh->RD, z);
+    else if constexpr (M::IM_TRI) M::im_solve_tri(sh->MF, z);
+    else M::im_solve(m, z);
+    fence();
+  }
 };

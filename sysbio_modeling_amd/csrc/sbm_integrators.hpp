@@ -1942,6 +1942,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
 }
 
 #include "sbm_implicit_adaptive.hpp"
+#include "sbm_implicit_extrap.hpp"
 #include "sbm_sens_mfma.hpp"
 
 // What the implicit kernels can hold: every lane keeps a whole column of S (NV values) and the solver's work vector
@@ -1963,6 +1964,22 @@ template <class M>
 static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t stream) {
   const sbm_kernel_args a = *args;
   if (a.n_traj <= 0) return (int)hipSuccess;
+  if (a.opts.method == SBM_IMPLICIT_EXTRAP) {
+    if constexpr (SbmIexFits<M>::value) {
+      const int nch = a.S ? (M::NK + 63) / 64 : 1;
+      if (nch > 1) {     // chunks combine status / counts with atomicMax
+        hipError_t e = hipSuccess;
+        if (a.status) e = hipMemsetAsync(a.status, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e == hipSuccess && a.n_steps) e = hipMemsetAsync(a.n_steps, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e == hipSuccess && a.n_reject) e = hipMemsetAsync(a.n_reject, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL((sbm_iex_kernel<M>), dim3(a.n_traj, nch), dim3(64), 0, stream, a);
+      return (int)hipGetLastError();
+    } else {
+      return (int)hipErrorInvalidConfiguration;
+    }
+  }
   if (a.opts.method == SBM_IMPLICIT_ADAPTIVE) {
     if constexpr (SbmImplicitFits<M>::adaptive) {
       const int nch = a.S ? (M::NK + 63) / 64 : 1;
