@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(64) sbm_iex_kernel(sbm_kernel_args a) {
           double yb[RPL];
 #pragma unroll
           for (int r = 0; r < RPL; ++r) yb[r] = fma(2.0, ya[r], -yp[r]);      // previous increment (first step: H/j * slope)
-          rc = st.template newton<8>(fma((double)(m + 1), h, t), h, ya, yb, nrtol, natol, n_newton);
+          rc = st.template newton_rate<8>(fma((double)(m + 1), h, t), h, ya, yb, nrtol, natol, n_newton);
           if (rc == SBM_OK) {
 #pragma unroll
             for (int r = 0; r < RPL; ++r) { yp[r] = ya[r]; ya[r] = yb[r]; }

@@ -81,6 +81,8 @@ struct SbmImplicitStepper {
 #endif
   static constexpr int MFSPARE = Sh::MF_SIZE - 1;
   double m[(DIST || M::IM_TRI) ? 1 : M::IM_NM];    // the redundant form's factors
+  static constexpr bool CHAIN = M::IM_CHAIN && RPL == 1 && !DIST;
+  double ch_a, ch_b;                               // CHAIN: this lane's row of the recurrence x_i = b_i + a_i x_{i-1}
 
   __device__ __forceinline__ static void fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 
@@ -250,6 +252,144 @@ struct SbmImplicitStepper {
     return SBM_NEWTON_FAIL;
   }
 
+  // ---- the same iteration in pieces (sbm_implicit_extrap.hpp) ----
+  // Evaluate f, J_y, J_p at yb (time tm): the Newton residual (yb - y) - hh f goes to G, J_p to A, and M = I - hh J_y is
+  // factored (MF / RD / m), ready for solve_delta() and the sensitivity solves.
+  __device__ __forceinline__ void eval_factor(double tm, double hh, const double (&y)[RPL], const double (&yb)[RPL]) {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) sh->Y[lane + 64 * r] = yb[r];
+    fence();
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      double ys[M::RL_MAXYS];
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXYS; ++q) ys[q] = sh->Y[yidx[r][q]];
+      double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJY; ++q) jy[q] = 0.0;
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJP; ++q) jp[q] = 0.0;
+      M::class_dispatch(cls[r], tm, ys, ps[r], f, jy, jp);
+      fence();
+#pragma unroll
+      for (int q = 0; q < M::RL_MAXJP; ++q) sh->A[apos[r][q]] = jp[q];
+      if constexpr (!M::IM_TRI && !DIST) {
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJY; ++q) sh->JY[jyout[r][q]] = jy[q];
+      }
+      sh->G[lane + 64 * r] = has_row[r] ? (yb[r] - y[r]) - hh * f : 0.0;
+      if constexpr (M::IM_TRI) {
+        double jd = 0.0;
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJY; ++q) jd = sbm_sel(diagslot[r] == q, jy[q], jd);
+        const double rd = sbm_rcp(fma(-hh, jd, 1.0));
+        sh->MF[rdpos[r]] = rd;
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJY; ++q) sh->MF[mfpos[r][q]] = hh * jy[q] * rd;
+        if constexpr (CHAIN) {
+          double off = 0.0;       // the one entry left of the diagonal (none in the first row)
+#pragma unroll
+          for (int q = 0; q < M::RL_MAXJY; ++q) off += sbm_sel(diagslot[r] == q, 0.0, jy[q]);
+          ch_a = has_row[r] ? hh * off * rd : 0.0;
+          ch_b = has_row[r] ? ((yb[r] - y[r]) - hh * f) * rd : 0.0;
+        }
+      } else if constexpr (DIST) {
+        factor_rows(hh, jy);
+      }
+    }
+    fence();
+    if constexpr (!M::IM_TRI && !DIST) {
+      M::im_build(hh, sh->JY, m);
+      M::im_factor(m);
+    }
+  }
+
+  // v of the lane `CTRL` names (DPP), `fill` where that lane does not exist or the row is masked off
+  template <int CTRL, int ROW_MASK>
+  __device__ __forceinline__ static double dpp_f64(double v, double fill) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+  // one level of the prefix: (a, b)_i <- (a, b)_i o (a, b)_src, i.e. x_i = b_i + a_i x_src expressed through x_(src's source)
+  template <int CTRL, int ROW_MASK>
+  __device__ __forceinline__ static void chain_level(double& a, double& b) {
+    const double ap = dpp_f64<CTRL, ROW_MASK>(a, 1.0), bp = dpp_f64<CTRL, ROW_MASK>(b, 0.0);
+    b = fma(a, bp, b);
+    a *= ap;
+  }
+
+  // d <- the components of this lane's rows of M^-1 G (the Newton update), with the factors eval_factor() left
+  __device__ __forceinline__ void solve_delta(double (&d)[RPL]) {
+    if constexpr (CHAIN) {
+      // x_i = b_i + a_i x_{i-1}, x_{-1} = 0: an inclusive prefix over the row lanes with the associative composition
+      // of affine maps, on DPP -- shifts by 1, 2, 4, 8 inside the rows of 16 lanes, then the last lane of a row to the
+      // row above (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3), as rocPRIM scans a wavefront.
+      // 36 instructions where the substitution every lane repeats for itself takes ~350 (50 rows).
+      double a = ch_a, b = ch_b;
+      chain_level<0x111, 0xf>(a, b);    // row_shr:1
+      chain_level<0x112, 0xf>(a, b);    // row_shr:2
+      chain_level<0x114, 0xf>(a, b);    // row_shr:4
+      chain_level<0x118, 0xf>(a, b);    // row_shr:8
+      if constexpr (NV > 16) chain_level<0x142, 0xa>(a, b);    // row_bcast:15
+      if constexpr (NV > 32) chain_level<0x143, 0xc>(a, b);    // row_bcast:31
+      d[0] = b;
+    } else if constexpr (M::IM_TRI && !DIST) {
+      // fused: a solution component lives in a register only while later rows refer to it (emit_implicit.py)
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) d[r] = 0.0;
+      int lo = lane;               // (opaque: the 2 NV lane masks are otherwise hoisted out of every loop and spilled)
+      asm volatile("" : "+v"(lo));
+      M::template im_solve_tri_pick<RPL>(sh->MF, sh->G, lo, d);
+      fence();
+    } else {
+      double b[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
+      if constexpr (DIST) M::im_solve_lds(sh->MF, sh->RD, b);
+      else M::im_solve(m, b);
+      fence();
+      sbm_static_for<RPL>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        constexpr int CNT = (NV - 64 * r) < 64 ? (NV - 64 * r) : 64;
+        d[r] = sbm_pick_slice<NV, 64 * r, CNT>(b, lane);
+      });
+    }
+  }
+
+  // Newton on yb as newton(), ended by the RATE of convergence: the updates fall quadratically, so once two of them
+  // are known the error of the iterate just formed is predicted as rr^2 * (rr / rr_prev^2) (in units of the
+  // tolerance); below 0.1 the iteration stops one solve early -- f, J_y, J_p are evaluated and M is factored at that
+  // iterate (the sensitivity solves want the matrices of the CONVERGED state: they are amplified by the extrapolation
+  // weights), the solve for an update that would change nothing is skipped.
+  template <int MAXIT>
+  __device__ __forceinline__ int newton_rate(double tm, double hh, const double (&y)[RPL], double (&yb)[RPL], double nrtol,
+                                             double natol, int& n_iter) {
+    float r_prev = 0.f;
+    for (int it = 0; it < MAXIT; ++it) {
+      ++n_iter;
+      eval_factor(tm, hh, y, yb);
+      double d[RPL];
+      solve_delta(d);
+      float rmax = 0.f;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const double dd = has_row[r] ? d[r] : 0.0;
+        yb[r] -= dd;
+        rmax = fmaxf(rmax, has_row[r] ? sbm_nan_to_inf((float)(fabs(dd) / fma(nrtol, fabs(yb[r]), natol))) : 0.f);
+      }
+      const float rr = sbm_wave_max(rmax);
+      if (!(rr < 3.0e38f)) return SBM_NON_FINITE;
+      if (rr <= 1.0f) return SBM_OK;
+      if (it > 0 && rr < 0.25f * r_prev && rr * rr * (rr / (r_prev * r_prev)) <= 0.1f) {
+        eval_factor(tm, hh, y, yb);
+        return SBM_OK;
+      }
+      r_prev = rr;
+    }
+    return SBM_NEWTON_FAIL;
+  }
+
   // J_p[i][this lane's column]
   __device__ __forceinline__ double a_of(int i) const {
     if constexpr (Sh::A_SPARSE) {
@@ -279,8 +419,20 @@ struct SbmImplicitStepper {
   // one implicit-EULER step (hh = the step) of a sensitivity column with the matrices newton() left, in place:
   // z <- M^-1 (z + hh J_p) -- the exact derivative of y_{n+1} = y_n + hh f(y_{n+1})  (sbm_implicit_extrap.hpp)
   __device__ __forceinline__ void sens_euler(double hh, double (&z)[NV]) {
+    if constexpr (Sh::A_SPARSE) {
+      int lo = lane + 64 * chunk;  // (opaque: see solve_delta)
+      asm volatile("" : "+v"(lo));
 #pragma unroll
-    for (int i = 0; i < NV; ++i) z[i] = fma(hh, a_of(i), z[i]);
+      for (int i = 0; i < NV; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJP; ++q) a = sbm_sel(M::rl_jpcol(q, i) == lo, sh->A[i * M::RL_MAXJP + q], a);
+        z[i] = fma(hh, a, z[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) z[i] = fma(hh, a_of(i), z[i]);
+    }
     if constexpr (DIST) M::im_solve_lds(sh->MF, sh->RD, z);
     else if constexpr (M::IM_TRI) M::im_solve_tri(sh->MF, z);
     else M::im_solve(m, z);

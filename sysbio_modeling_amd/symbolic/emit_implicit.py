@@ -195,11 +195,40 @@ def emit_members(spec, d):
                 # keep the compiler from hoisting every table load to the top (2*IM_NM live registers)
                 L.append("    SBM_LDS_FENCE();")
         L += ["  }"]
+        # The Newton update of the STATE: the right-hand side is wave-uniform (every lane solves the same system) and a
+        # lane keeps only the components of its own rows.  Fused form: g_i is read when row i is due, x_i is handed to
+        # its lane (row i lives on lane i mod 64, slot i / 64) and stays in a register only while later rows refer to
+        # it -- the plain form keeps all NV values alive up to the final pick, NV register pairs that the
+        # extrapolation kernel needs for its running sums (sbm_implicit_extrap.hpp).
+        last_use = {}
+        for (r, c) in pattern:
+            if c < r:
+                last_use[c] = max(last_use.get(c, c), r)
+        L += ["  // x = M^-1 g for the wave-uniform g (LDS); d[i / 64] of lane i mod 64 <- x_i",
+              "  template <int RPL>",
+              "  __device__ __forceinline__ static void im_solve_tri_pick(const double* mf, const double* g, int lane, double (&d)[RPL]) {"]
+        for i in range(n):
+            expr = "mf[%d] * g[%d]" % (rstart[i], i)
+            for (r, c) in pattern:
+                if r == i and c < i:
+                    expr = "fma(mf[%d], x_%d, %s)" % (pos[(r, c)], c, expr)
+            L.append("    const double x_%d = %s;" % (i, expr))
+            L.append("    d[%d] = SBM_SEL(lane == %d, x_%d, d[%d]);" % (i // 64, i % 64, i, i // 64))
+            if i % 8 == 7 and i + 1 < n:
+                L.append("    SBM_LDS_FENCE();")
+        L += ["  }"]
         L += ["  static constexpr int IM_MF = %d;     // entries of the table (rows padded to even starts)" % n_table]
+        # a CHAIN (row i refers to row i - 1 only: a cascade): the Newton update of the state is a first-order linear
+        # recurrence x_i = b_i + a_i x_{i-1} over the row lanes -- a parallel prefix (sbm_implicit_stepper.hpp)
+        chain = n <= 64 and all(c == r or c == r - 1 for (r, c) in pattern)
+        L += ["  static constexpr bool IM_CHAIN = %s;" % ("true" if chain else "false")]
         L += emit_distributed(spec, d, pattern, ops)
         return L, dict(tri=True, rstart=rstart, pos=pos, nm=n_table)
     L += ["  __device__ __forceinline__ static void im_solve_tri(const double*, double (&)[NV]) {}",
-          "  static constexpr int IM_MF = IM_NM;"]
+          "  template <int RPL>",
+          "  __device__ __forceinline__ static void im_solve_tri_pick(const double*, const double*, int, double (&)[RPL]) {}",
+          "  static constexpr int IM_MF = IM_NM;",
+          "  static constexpr bool IM_CHAIN = false;"]
     L += emit_distributed(spec, d, pattern, ops)
     return L, dict(tri=False, nm=nm)
 
