@@ -11,6 +11,7 @@ from oracle.tolerances import parity_err
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 orders = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else '8').split(',')]
 rtols = [float(x) for x in (sys.argv[3] if len(sys.argv) > 3 else '3e-9').split(',')]
+atol_abs = float(sys.argv[4]) if len(sys.argv) > 4 else None
 gm = zoo_model('stiff50')
 ctx = _lib.default_context()
 lm = _lib.LoadedModel(ctx, gm.plugin_path(build_if_missing=True))
@@ -25,7 +26,7 @@ S = torch.empty((V, len(t_out), 50, 50), device=dev, dtype=torch.float64)
 st = torch.zeros(V, device=dev, dtype=torch.int32); ns = torch.zeros_like(st); nr = torch.zeros_like(st)
 for K in orders:
     for rtol in rtols:
-        o = _lib.make_opts('implicit_extrap', rtol=rtol, atol=1e-3 * rtol, order=K)
+        o = _lib.make_opts('implicit_extrap', rtol=rtol, atol=atol_abs if atol_abs else 1e-3 * rtol, order=K)
         Yh, Sh, sth, nsh, nrh = lm.sens_host(g['P'], t_out, None, o)
         Sh = Sh.reshape(Sh.shape[0], Sh.shape[1], -1)
         print('K %d rtol %g golden: status %s steps %s rej %s | vs ref y %.3f S %.3f | vs tight y %.3f S %.3f' % (
@@ -34,8 +35,9 @@ for K in orders:
             torch.cuda.synchronize(); t0 = time.time()
             lm.sens_dev(Pd, td, None, o, Y, S, st, ns, nr)
             torch.cuda.synchronize(); dt = time.time() - t0
-        print('   V %d sens: %.3f s; status!=0: %d; steps mean %.1f max %d rej mean %.1f' % (
-            V, dt, int((st != 0).sum()), ns.double().mean().item(), ns.max().item(), nr.double().mean().item()), flush=True)
+        print('   V %d sens: %.3f s; status!=0: %d; steps mean %.1f max %d rej mean %.1f (with SBM_IEX_COUNT_NEWTON: evaluations; %.2f per Euler step if no rejections)' % (
+            V, dt, int((st != 0).sum()), ns.double().mean().item(), ns.max().item(), nr.double().mean().item(),
+            nr.double().mean().item() / (ns.double().mean().item() * K * (K + 1) / 2)), flush=True)
         torch.cuda.synchronize(); t0 = time.time()
         lm.simulate_dev(Pd, td, None, o, Y, st, ns, nr)
         torch.cuda.synchronize(); dt = time.time() - t0

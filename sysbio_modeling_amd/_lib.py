@@ -142,9 +142,13 @@ def dev_ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-IMPLICIT_ADAPTIVE = ('implicit_adaptive', 'imid_adaptive', 'implicit_controlled', 'implicit_auto')
-# extrapolated implicit Euler with local step-size control (csrc/sbm_implicit_extrap.hpp): THE stiff integrator since round 3
-IMPLICIT_EXTRAP = ('implicit_extrap', 'implicit', 'stiff', 'seulex', 'extrapolated_euler', 'implicit_euler_extrap')
+# implicit midpoint, three solutions on uniform grids, restarts (csrc/sbm_implicit_adaptive.hpp): round 2's stiff integrator
+IMPLICIT_ADAPTIVE = ('implicit_adaptive', 'imid_adaptive', 'implicit_midpoint_controlled')
+# extrapolated implicit Euler with LOCAL step-size control (csrc/sbm_implicit_extrap.hpp): THE stiff integrator since
+# round 3 -- what 'implicit_controlled' / 'implicit' / 'stiff' name and what method='auto' falls back to
+IMPLICIT_EXTRAP = ('implicit_extrap', 'implicit_controlled', 'implicit', 'stiff', 'implicit_auto', 'seulex',
+                   'extrapolated_euler')
+STIFF_METHOD = 'implicit_extrap'
 IMPLICIT_GRADED = ('implicit_midpoint_graded', 'imid_graded')
 FIXED_STEP_IMPLICIT = ('implicit_midpoint', 'imid', 'midpoint') + IMPLICIT_GRADED
 VARIANTS = {'auto': 0, 'per_wave': 1, 'row_lane': 2, 'row_group': 3, 'small_batch': 4, 'mfma': 5, 'packed': 6}
@@ -166,6 +170,19 @@ def implicit_adaptive_defaults(o, explicit):
         # therefore cut by ten -- a third more steps (tolerance^(-1/8)), still a sixth of DOPRI45's.
         if 'rtol' not in explicit:
             o['rtol'] = 0.1 * float(o.get('rtol', 1e-9))
+        return o
+    if str(o.get('method', '')).lower() in IMPLICIT_EXTRAP:
+        # Extrapolated implicit Euler: the estimate is the difference of the order-K and order-(K-1) results of a step,
+        # the order-K result is what continues, and the GLOBAL error that accumulates comes out at 1 - 2 x rtol on the
+        # stiff models of the test-suite (stiff50, 35 vectors of the ensemble: worst sensitivity entry 0.5 parity units
+        # = 5e-9 relative at rtol 3e-9 against a tight solution).  Inherited defaults (rtol 1e-9 x size factor, atol
+        # 1e-18: the explicit integrator's) become rtol 3e-9, atol 1e-3 rtol, no step budget.
+        if 'rtol' not in explicit:
+            o['rtol'] = max(float(o.get('rtol', 1e-9)), 3e-9)
+        if 'atol' not in explicit:
+            o['atol'] = max(float(o.get('atol', 1e-12)), 1e-3 * float(o['rtol']))
+        if 'max_steps' not in explicit:
+            o['max_steps'] = 0
         return o
     if str(o.get('method', '')).lower() in IMPLICIT_ADAPTIVE:
         if 'rtol' not in explicit:

@@ -648,9 +648,9 @@ class Project(object):
         else:
             budget = abs(int(o.get('max_steps') or 0)) or 50000
             def implicit(idx):
-                # one device call: the implicit integrator with in-kernel error control (SBM_IMPLICIT_ADAPTIVE)
+                # one device call: the implicit integrator with local error control in the kernel (SBM_IMPLICIT_EXTRAP)
                 t = th[torch.as_tensor(idx, device=th.device, dtype=torch.long)]
-                oi = _lib.implicit_adaptive_defaults(dict(method='implicit_adaptive', rtol=rtol, atol=atol),
+                oi = _lib.implicit_adaptive_defaults(dict(method=o.get('stiff_method', _lib.STIFF_METHOD), rtol=rtol, atol=atol),
                                                      set(integrator_overrides) | set(self.integrator_options))
                 oi['max_steps'] = 0          # the budget belongs to the explicit attempt; the kernel's own limit here
                 return split(self._evaluate_once(t, jacobian, want, extrapolate=0, **oi, **keep)) + (None,)

@@ -164,20 +164,21 @@ def test_graded_start_keeps_fourth_order_after_extrapolation(gpu_models, golden)
 
 
 def test_in_kernel_controlled_implicit_integrator(gpu_models, golden):
-    """method='implicit_controlled' (= 'implicit_adaptive', SBM_IMPLICIT_ADAPTIVE): ONE device call, the step count
-    found inside the kernel (csrc/sbm_implicit_adaptive.hpp).  With default options the stiff50 golden vectors meet
-    the parity tolerance against the real reference's LSODA results -- where LSODA's own error (about one tolerance
-    unit on this model) gets in the way, against the tight LSODA solution of tests/golden/stiff50_tight.npz."""
+    """method='implicit_controlled' (= 'implicit_extrap', SBM_IMPLICIT_EXTRAP since round 3): ONE device call, every
+    trajectory's step sizes chosen by LOCAL error control inside the kernel (csrc/sbm_implicit_extrap.hpp).  With
+    default options the stiff50 golden vectors meet the parity tolerance against the real reference's LSODA results --
+    where LSODA's own error (about one tolerance unit on this model) gets in the way, against the tight LSODA solution
+    of tests/golden/stiff50_tight.npz."""
     m = gpu_models('stiff50')
     g, gt = golden('stiff50_ref.npz'), golden('stiff50_tight.npz')
     P = g['P']
     t_out = _from_zero(g['t'][g['idx']])
     S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled')
     info = m.last_info
-    assert info['status'].tolist() == [0, 0, 0] and np.all(info['n_steps'] >= 64)
+    assert info['status'].tolist() == [0, 0, 0] and np.all(info['n_steps'] >= 16)
     ey = check_parity(Y[:, 1:], g['Y'], gt['Y'], what='stiff50 states', criterion='parity')
     es = check_parity(S[:, 1:], g['S'], gt['S'], what='stiff50 sensitivities', criterion='parity')
-    print("implicit_controlled on stiff50: %s coarse steps (+%s in abandoned passes); error vs LSODA golden y %.2f S %.2f"
+    print("implicit_controlled on stiff50: %s macro steps (+%s rejected); error vs LSODA golden y %.2f S %.2f"
           % (info['n_steps'], info['n_rejected'], ey[0], es[0]), "vs tight:", ey[1], es[1])
     # state only: the same controller without the column work
     Y1 = m.simulate_batch(P, t_out, method='implicit_controlled')
@@ -191,7 +192,7 @@ def test_in_kernel_controlled_implicit_integrator(gpu_models, golden):
     # a step budget too small for the tolerance is reported, rows NaN
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        Y3 = m.simulate_batch(P[:1], t_out, method='implicit_controlled', max_steps=100)
+        Y3 = m.simulate_batch(P[:1], t_out, method='implicit_controlled', max_steps=20)
     assert m.last_info['status'].tolist() == [1] and np.all(np.isnan(Y3[0, -1]))
 
 
@@ -479,8 +480,13 @@ def test_eighty_state_stiff_cascade_against_reference_golden(golden):
 
 
 def test_controlled_implicit_kernel_on_a_seventy_state_model_agrees_with_dopri45():
-    """cascade70 (not stiff): the error-controlled implicit kernel and DOPRI45 at their default options solve the same
-    problem -- state and all 70 x 140 sensitivities -- to the parity tolerance."""
+    """cascade70 (not stiff): the error-controlled implicit kernel and DOPRI45 solve the same problem -- state and all
+    70 x 140 sensitivities -- to the parity tolerance.  The cascade is an AMPLIFIER (gain k/d = 5 - 10 per stage while a
+    stage is far from saturation): the relative error of a component that is still tiny reaches every stage downstream,
+    so the test has to be relative -- DOPRI45's default atol is 1e-18 for that reason (model/ode_model.py) and the
+    implicit kernel, whose inherited atol is 1e-3 rtol (stiff models carry sensitivities that are numerical noise:
+    _lib.implicit_adaptive_defaults), is given the same here.  With the default atol it is 240 parity units off on this
+    model -- as the reference's LSODA at atol 1e-10 is (310 units)."""
     from sysbio_modeling_amd import models_zoo
     gm, m = _big_model('cascade', 70)
     rng = np.random.default_rng(70)
@@ -488,10 +494,10 @@ def test_controlled_implicit_kernel_on_a_seventy_state_model_agrees_with_dopri45
     t_out = np.array([0.0, 10.0, 30.0, 60.0])
     Se, Ye = m.calc_jacobian_batch(P, t_out, return_states=True)
     assert not m.last_info['status'].any()
-    Si, Yi = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled')
+    Si, Yi = m.calc_jacobian_batch(P, t_out, return_states=True, method='implicit_controlled', rtol=1e-9, atol=1e-18)
     assert not m.last_info['status'].any()
     ey, es = parity_err(Yi[:, 1:], Ye[:, 1:]), parity_err(Si[:, 1:], Se[:, 1:])
-    print("cascade70 implicit_controlled vs dopri45: y %.3f S %.3f units, %s coarse steps" % (ey, es, m.last_info['n_steps']))
+    print("cascade70 implicit_controlled vs dopri45: y %.3f S %.3f units, %s macro steps" % (ey, es, m.last_info['n_steps']))
     assert ey <= 1.0 and es <= 1.0
 
 
