@@ -199,12 +199,88 @@ def self_launch(n_gpus):
 # ---------------------------------------------------------------------------
 # rooflines
 # ---------------------------------------------------------------------------
+_CURRENT_STAMPS = {}      # module name -> build stamp of what this process runs (filled by main / the runners)
+
+
 def _counters():
+    """profiles/kernel_counters.json, minus the entries whose module (core library / model plugin) has been rebuilt
+    from different sources since the profile was taken: stale counters are dropped, not printed."""
     try:
         with open(COUNTERS) as fh:
-            return json.load(fh)
+            raw = json.load(fh)
     except (OSError, ValueError):
         return {}
+    out = {}
+    for key, e in raw.items():
+        mod, st = e.get('module'), e.get('build_stamp')
+        if mod is None or st is None or _CURRENT_STAMPS.get(mod) != st:
+            continue
+        out[key] = e
+    return out
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X: half the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md (SURVEY.md section 8(d))
+
+
+def flops_per_step(gm, method, sens=True, evals_per_step=None):
+    """USEFUL fp64 operations of one accepted step of one trajectory, from the emitter's own operation counts
+    (GeneratedModel.flop_counts): right-hand-side evaluations + J_y S products + the method's linear combinations.
+    Selects, the step controller, LDS hand-offs and redundant work are NOT counted -- that is the point of the figure.
+    Returns (F_step, formula)."""
+    c = gm.flop_counts()
+    n, k = gm.n_vars, (gm.n_sens if sens else 0)
+    N = n * (1 + k)
+    if sens:
+        rhs = c['f_jac'] + 2 * c['nnz_jy'] * k + c['nnz_jp']
+        rhs_txt = "(f + J_y + J_p: %d) + 2 nnz(J_y) k (%d) + nnz(J_p) (%d)" % (c['f_jac'], 2 * c['nnz_jy'] * k, c['nnz_jp'])
+    else:
+        rhs = c['f']
+        rhs_txt = "f: %d" % c['f']
+    if method == 'dopri45':      # 21 a_ij + 7 b_j (the FSAL stage argument) + the error estimate's e_j: 38 multiply-adds per element
+        return 6 * rhs + 2 * 38 * N, "6 stages x [%s] + 38 multiply-adds x %d elements (21 a_ij, 7 b_j, 7 e_j, accept / scale)" % (rhs_txt, N)
+    if method == 'dop853':       # 50 a_ij, 8 b_j, 8 + 8 coefficients of the two embedded estimates
+        return 12 * rhs + 2 * 74 * N, "12 stages x [%s] + 74 multiply-adds x %d elements" % (rhs_txt, N)
+    if method == 'rk4':
+        return 4 * rhs + 2 * 8 * N, "4 stages x [%s] + 8 multiply-adds x %d elements" % (rhs_txt, N)
+    if method in ('implicit_euler', 'implicit_midpoint'):
+        # one implicit step: `evals_per_step` Newton evaluations of f / J_y / J_p, each with one solve of the sparse
+        # factors (2 nnz(L + U) - n operations) for the state, + one such solve and the J_p term per sensitivity column
+        ev = float(evals_per_step or 1.0)
+        solve = 2 * c['nnz_lu'] - n
+        F = ev * (c['f_jac'] + solve + 2 * n) + k * (solve + (2 if method == 'implicit_midpoint' else 0) * n) + 2 * c['nnz_jp']
+        return F, ("%.2f Newton evaluations x [(f + J_y + J_p: %d) + one sparse solve (%d) + residual (%d)] + %d columns x "
+                   "one sparse solve + 2 nnz(J_p)" % (ev, c['f_jac'], solve, 2 * n, k))
+    raise ValueError(method)
+
+
+def fp64_rate(flops_step, formula, steps_per_s):
+    t = flops_step * steps_per_s / 1e12
+    return {"achieved": t, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": t / FP64_VECTOR_PEAK_TFLOPS,
+            "useful_flops_per_step": flops_step, "formula": formula,
+            "note": "USEFUL operations only (emitter's operation counts: right-hand sides, J_y S, the method's linear "
+                    "combinations) against the fp64 vector peak; what the kernel ISSUES is roofline_valu_issue"}
+
+
+def build_stamps(*models):
+    """Fingerprints (flags + toolchain + source contents: sysbio_modeling_amd/build.py) of the native modules whose
+    kernels the rooflines quote PMC counters for.  profiles/kernel_counters.json stores them next to every entry
+    (scripts/summarize_profile.py); an entry whose module has been rebuilt since is NOT printed."""
+    from sysbio_modeling_amd import build
+    out = {}
+
+    def stamp(path):
+        try:
+            with open(path + '.stamp') as fh:
+                return fh.read().strip()[:16]
+        except OSError:
+            return None
+    out['core'] = stamp(build.CORE_LIB)
+    for gm in models:
+        try:
+            out[gm.name] = stamp(gm.plugin_path(build_if_missing=False))
+        except Exception:   # noqa: BLE001
+            out[gm.name] = None
+    return out
 
 
 def hbm_roofline(kernel, key, k_ms, k_steps, bytes_per_step, note):
@@ -332,9 +408,10 @@ def main():
     gm = zoo_model('cascade20')
     model = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, use_jit=False)
     model.enable_jit(_lib.Context(local_rank))
+    _CURRENT_STAMPS.update(build_stamps(gm))
     if args.only not in (None, 'headline'):
         out = bc.RUNNERS[args.only](model, gm, dev, reps=max(1, args.steps), cpu=False)
-        emit({args.only: out})
+        emit({args.only: out, "build": dict(_CURRENT_STAMPS)})
         return
     V = args.vectors
     proj, theta, t_meas = build_workload(model, gm, V, rank)
@@ -399,7 +476,7 @@ def main():
     value = total_steps_per_pass * args.steps / dt
     if args.only == 'headline':
         emit({"headline": {"ms_per_step": 1e3 * dt / args.steps, "value": value,
-                           "steps_per_pass": total_steps_per_pass}})
+                           "steps_per_pass": total_steps_per_pass}, "build": dict(_CURRENT_STAMPS)})
         return
 
     # ---- SURVEY.md section 8(d)'s host-inclusive figure: P upload and download of the sampled rows / norms ----
@@ -455,6 +532,7 @@ def main():
                             "state in VGPRs, so real HBM traffic ('traffic', PMC) is far below this figure and the "
                             "binding resource is VALU issue: see roofline_valu_issue")
     roofline_valu = valu_roofline(kkey, k_ms, k_steps)
+    roofline["achieved_fp64"] = fp64_rate(*flops_per_step(gm, args.method), k_steps / (k_ms * 1e-3))
 
     result = {
         "metric": "ensemble ODE-steps/sec (20-state model + fwd sens)",
@@ -505,6 +583,7 @@ def main():
         except Exception as e:   # noqa: BLE001
             result["extras"] = {"error": repr(e)[:300]}
     if rank == 0:
+        result["build"] = dict(_CURRENT_STAMPS)
         emit(result)
     if world > 1:
         dist.barrier()   # rank 0 arrives late

@@ -54,6 +54,8 @@ def run_configs1(model, gm, dev, reps=3, cpu=True):
                                         ms, steps, 2 * 8 * 20,
                                         "SURVEY.md section 8(d): 320 B per accepted step (read + write 20 doubles); the "
                                         "state lives in registers, real traffic is the parameter load and 17 output rows")}
+        r["roofline"]["achieved_fp64"] = B.fp64_rate(*B.flops_per_step(gm, 'dopri45' if label == 'dopri45' else 'rk4', sens=False),
+                                                     steps / (ms * 1e-3))
         rv = B.valu_roofline('state_packed_cascade20_' + label, ms, steps)
         if rv:
             r["roofline_valu_issue"] = rv
@@ -110,24 +112,18 @@ def run_configs3(model, gm, dev, reps=3, cpu=True):
                                       k_ms, k_steps, B.BYTES_PER_STEP,
                                       "the pass's integrator launch alone (8192 trajectories), 13 120 B per accepted step"),
            "integrator_share_of_pass": k_ms / ms}
+    out["roofline"]["achieved_fp64"] = B.fp64_rate(*B.flops_per_step(gm, 'dopri45'), k_steps / (k_ms * 1e-3))
     rv = B.valu_roofline('sens_rowgroup_cascade20_dopri45', k_ms, k_steps)
     if rv:
         out["roofline_valu_issue"] = rv
     if cpu:
-        from oracle import tolerances as tol
         po = B.project_oracle_of(gm, p4)
-        # parity of the timed pass on two vectors, then the timed sample
+        # parity of the timed pass on 32 vectors spread over the batch (a pool of spawned workers runs the oracle on
+        # them), then the timed one-core sample
         R = o4['residuals'].cpu().numpy()
         J = o4['jacobian'].cpu().numpy()
-        worst = [0.0, 0.0]
-        for v in (0, V - 1):
-            rr, sims, Bf = po.residuals(thetas[v], return_parts=True)
-            Jm = po.model_jacobian(thetas[v])
-            Jr = po.calc_project_jacobian(thetas[v])
-            ts, tj = tol.lsoda_taus(a, thetas[v], sims, Jm)
-            t = tol.project_tolerances(a, sims, Bf, ts, Jm, tj)
-            worst[0] = max(worst[0], tol.tol_ratio(R[v], rr, t['residuals']))
-            worst[1] = max(worst[1], tol.tol_ratio(J[v], Jr, t['jacobian']))
+        picks = [int(x) for x in np.linspace(0, V - 1, 32).astype(int)]
+        parity = oracle_parity_pool(p4, a, thetas, R, J, picks)
         po.lsoda_steps = 0
         n, t0 = 0, time.perf_counter()
         for v in range(1, V - 1):
@@ -142,18 +138,199 @@ def run_configs3(model, gm, dev, reps=3, cpu=True):
                       "rtol=atol=1e-10 on the 1000-point grid per experiment + numpy assembly; %.1f s, %d LSODA steps"
                       % (n, dt, po.lsoda_steps),
             "ms_per_vector": 1e3 * dt / max(n, 1),
-            "parity_of_timed_pass": {"vectors_checked": 2, "residual_err_in_tolerance_units": worst[0],
-                                     "jacobian_err_in_tolerance_units": worst[1],
-                                     "tolerance": "oracle/tolerances.py::project_tolerances over lsoda_taus"}}
+            "parity_of_timed_pass": parity}
     return out
+
+
+def _oracle_rows(args):
+    """one worker of oracle_parity_pool: the assembly oracle (SciPy odeint per experiment + numpy assembly) on its share"""
+    experiments, settings, mapping, sf_groups, rows = args
+    from sysbio_modeling_amd.symbolic import zoo_model
+    from oracle.project_oracle import ProjectOracle
+    po = ProjectOracle(zoo_model('cascade20'), experiments, settings, mapping, sf_groups=sf_groups)
+    out = []
+    for th in rows:
+        rr, sims, Bf = po.residuals(th, return_parts=True)
+        out.append((rr, sims, Bf, po.model_jacobian(th), po.calc_project_jacobian(th)))
+    return out
+
+
+def oracle_parity_pool(proj, a, thetas, R, J, picks):
+    """Residual / Jacobian rows of a timed GPU pass against the assembly oracle for the vectors `picks`, the oracle runs
+    spread over the host cores (spawned workers; the oracle of one 8-experiment vector costs ~2.5 s of one core)."""
+    import multiprocessing as mp
+    import os
+    from oracle import tolerances as tol
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16, len(picks)))
+    sf_groups = [g if len(g) > 1 else g[0] for g in proj._loss_function.groups]
+    shares = [picks[i::cores] for i in range(cores)]
+    jobs = [(list(proj.experiments), proj._model_parameter_settings, dict(proj._measurement_to_model_map_raw), sf_groups,
+             [thetas[v] for v in sh]) for sh in shares]
+    t0 = time.perf_counter()
+    with mp.get_context('spawn').Pool(cores) as pool:
+        res = pool.map(_oracle_rows, jobs)
+    worst_r = worst_j = 0.0
+    worst_v = [None, None]
+    for sh, rows in zip(shares, res):
+        for v, (rr, sims, Bf, Jm, Jr) in zip(sh, rows):
+            ts, tj = tol.lsoda_taus(a, thetas[v], sims, Jm)
+            t = tol.project_tolerances(a, sims, Bf, ts, Jm, tj)
+            er, ej = tol.tol_ratio(R[v], rr, t['residuals']), tol.tol_ratio(J[v], Jr, t['jacobian'])
+            if er > worst_r:
+                worst_r, worst_v[0] = er, v
+            if ej > worst_j:
+                worst_j, worst_v[1] = ej, v
+    return {"vectors_checked": len(picks), "residual_err_in_tolerance_units": worst_r, "jacobian_err_in_tolerance_units": worst_j,
+            "worst_vectors": worst_v, "oracle_wall_seconds": time.perf_counter() - t0, "oracle_worker_processes": cores,
+            "tolerance": "oracle/tolerances.py::project_tolerances over lsoda_taus (trajectories within 1e-8 |ref| + 5e-9 "
+                         "of the reference's LSODA, propagated to first order through the reference's formulas); <= 1 passes. "
+                         "A vector slightly above 1 in the Jacobian is LSODA's own error (tests/test_gpu_parity_sweeps.py "
+                         "arbitrates such vectors against the oracle driven by a tight integrator)"}
 
 
 # ---------------------------------------------------------------------------
 # configs[4]: stiff 50-state cascade (2550 coupled ODEs), 4096 vectors
 # ---------------------------------------------------------------------------
-def stiff_pass(torch, dev, dm, P5, t5, bufs):
-    """One evaluation of the 4096-vector stiff ensemble AT THE PARITY-MEETING SETTING (tests/test_gpu_implicit.py:
-    within 1e-8 |ref| + 5e-9 of the real reference's LSODA results): see STIFF_SETTING."""
+IEX_ORDER = 8
+STIFF_SETTING = ("extrapolated implicit Euler (SBM_IMPLICIT_EXTRAP, order 8: 36 implicit-Euler steps per macro step), "
+                 "LOCAL error control in the kernel at the method's default tolerances, ONE launch, no step count chosen")
+STIFF_FIXED_SETTING = "implicit midpoint, 4096 + 8192 fixed steps, Richardson-extrapolated on the device (round 2's timed setting)"
+
+
+def _stiff_setup(model, dev, V=4096):
+    import os
+    import torch
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.symbolic import zoo_model
+    from sysbio_modeling_amd.model import OdeModel
+    gm5 = zoo_model('stiff50')
+    m5 = OdeModel(gm5.model, gm5.sens_model, gm5.n_vars, gm5.param_order, use_jit=False)
+    m5.enable_jit(model.device_model.ctx)
+    B._CURRENT_STAMPS.update(B.build_stamps(gm5))
+    theta5, Pn = models_zoo.stiff_ensemble(V)
+    gdir = os.path.join(B.REPO, 'tests', 'golden')
+    g = np.load(os.path.join(gdir, 'stiff50_ref.npz'))
+    assert np.array_equal(Pn[:3], g['P'])
+    P5 = torch.from_numpy(Pn).to(dev)
+    t_np = np.concatenate([[0.0], g['t'][g['idx']]])
+    t5 = torch.from_numpy(t_np).to(dev)
+    return gm5, m5, Pn, P5, t_np, t5, gdir
+
+
+def stiff_golden_parity(gdir, Pn, Yg, Sg):
+    """Parity of a timed configs[4] pass against every stiff50 vector the REAL reference OdeModel was run on
+    (tests/golden/stiff50_ref.npz: vectors 0-2 of the ensemble; stiff50_wide_ref.npz: 32 more spread over it,
+    make_golden_stiff_wide.py), arbitrated -- where the reference's own LSODA run is the one that is off -- by the tight
+    LSODA solutions (stiff50_tight.npz, stiff50_wide_tight.npz) exactly as tests/conftest.py::check_parity does:
+    a vector passes if it is within |gpu - ref| <= 1e-8 |ref| + 5e-9 of the reference's result, or within that of the
+    tight solution AND closer to it than the reference's result is."""
+    import os
+    from oracle.tolerances import parity_err
+    sets = [('stiff50_ref.npz', 'stiff50_tight.npz', np.arange(3), None)]
+    if os.path.exists(os.path.join(gdir, 'stiff50_wide_ref.npz')):
+        w = np.load(os.path.join(gdir, 'stiff50_wide_ref.npz'))
+        sets.append(('stiff50_wide_ref.npz', 'stiff50_wide_tight.npz', w['index'], None))
+    worst = {'state_vs_reference': 0.0, 'sens_vs_reference': 0.0, 'state_vs_tight': 0.0, 'sens_vs_tight': 0.0}
+    n_checked = n_tight = n_arbitrated = n_failed = 0
+    for ref_name, tight_name, index, _ in sets:
+        g = np.load(os.path.join(gdir, ref_name))
+        tight = np.load(os.path.join(gdir, tight_name)) if os.path.exists(os.path.join(gdir, tight_name)) else None
+        trow = {}
+        if tight is not None:
+            rows = tight['rows'] if 'rows' in tight.files else np.arange(len(tight['P']))
+            trow = {int(r): i for i, r in enumerate(rows)}
+        assert np.array_equal(Pn[index], g['P'])
+        nt = g['Y'].shape[1]
+        for j, v in enumerate(index):
+            Y = Yg[int(v), 1:].cpu().numpy()
+            S = Sg[int(v), 1:].cpu().numpy().reshape(nt, -1)
+            ey, es = parity_err(Y, g['Y'][j]), parity_err(S, g['S'][j])
+            worst['state_vs_reference'] = max(worst['state_vs_reference'], ey)
+            worst['sens_vs_reference'] = max(worst['sens_vs_reference'], es)
+            n_checked += 1
+            ok = ey <= 1.0 and es <= 1.0
+            if j in trow:
+                i = trow[j]
+                n_tight += 1
+                ty, ts = parity_err(Y, tight['Y'][i]), parity_err(S, tight['S'][i])
+                worst['state_vs_tight'] = max(worst['state_vs_tight'], ty)
+                worst['sens_vs_tight'] = max(worst['sens_vs_tight'], ts)
+                if not ok:
+                    ly, ls = parity_err(g['Y'][j], tight['Y'][i]), parity_err(g['S'][j], tight['S'][i])
+                    ok = ty <= 1.0 and ts <= 1.0 and ty <= max(ly, 1e-3) and ts <= max(ls, 1e-3)
+                    n_arbitrated += int(ok)
+            n_failed += int(not ok)
+    return {"vectors_checked": n_checked, "vectors_with_a_tight_solution": n_tight,
+            "worst_state_err_vs_reference_in_tolerance_units": worst['state_vs_reference'],
+            "worst_sens_err_vs_reference_in_tolerance_units": worst['sens_vs_reference'],
+            "worst_state_err_vs_tight_solution": worst['state_vs_tight'],
+            "worst_sens_err_vs_tight_solution": worst['sens_vs_tight'],
+            "vectors_passed_by_arbitration": n_arbitrated, "vectors_failed": n_failed,
+            "tolerance": "|gpu - ref| <= 1e-8 |ref| + 5e-9 against the real reference OdeModel's results (LSODA at rtol = "
+                         "atol = 1e-10, itself about one unit off its own tight solution on this model); a vector beyond "
+                         "that must be within it of the tight solution and closer to it than the reference is",
+            "note": "vs-reference figures above 1 with vectors_failed = 0 are the reference's own LSODA error"}
+
+
+def run_configs4(model, gm, dev, reps=3, cpu=True):
+    """BASELINE configs[4] at the product's DEFAULT options for a stiff model: what method='auto' / 'implicit_controlled'
+    run -- SBM_IMPLICIT_EXTRAP with the tolerances _lib.implicit_adaptive_defaults derives (no hand-chosen step count)."""
+    import torch
+    from sysbio_modeling_amd import _lib
+    gm5, m5, Pn, P5, t_np, t5, gdir = _stiff_setup(model, dev)
+    dm = m5.device_model
+    V, nt = Pn.shape[0], len(t_np)
+    f64, i32 = torch.float64, torch.int32
+    Y = torch.empty((V, nt, 50), dtype=f64, device=dev)
+    S = torch.empty((V, nt, 50, 50), dtype=f64, device=dev)
+    st, ns, nr = (torch.empty((V,), dtype=i32, device=dev) for _ in range(3))
+    o = dict(m5.integrator_options, method='implicit_extrap')
+    _lib.implicit_adaptive_defaults(o, ())
+    tol = {k: o[k] for k in ('rtol', 'atol')}
+    opts = _lib.make_opts('implicit_extrap', order=IEX_ORDER, **tol)
+    ms = _events(torch, dev, lambda: dm.sens_dev(P5, t5, None, opts, Y, S, st, ns, nr), reps)
+    macro, rej = int(ns.sum().item()), int(nr.sum().item())
+    euler = (macro + rej) * (IEX_ORDER * (IEX_ORDER + 1) // 2)
+    failed = int((st != 0).sum().item())
+    # state only, the same options (every residual-only evaluation of a stiff Project)
+    ms_state = _events(torch, dev, lambda: dm.simulate_dev(P5, t5, None, opts, Y, st, ns, nr), reps)
+    macro_state = int(ns.sum().item())
+    dm.sens_dev(P5, t5, None, opts, Y, S, st, ns, nr)      # (Y of the sensitivity pass again, for the parity check)
+    evals = 2.9      # Newton evaluations per Euler step (measured: profiles/r03, developer build SBM_IEX_COUNT_NEWTON)
+    F, formula = B.flops_per_step(gm5, 'implicit_euler', evals_per_step=evals)
+    out = {"workload": "configs[4]: stiff50 (50 states, 50 sensitivity parameters: 2550 coupled ODEs, rates spanning "
+                       "1e6), 4096 vectors, 16 output times, " + STIFF_SETTING + " (rtol %g, atol %g)" % (tol['rtol'], tol['atol']),
+           "ms": ms, "macro_steps": macro, "rejected_macro_steps": rej, "euler_steps": euler, "steps": euler,
+           "value": euler / (ms * 1e-3), "unit": "ODE-steps/s",
+           "unit_note": "a step = one implicit-Euler step of the 2550-equation system (Newton on the 50 states + one sparse "
+                        "solve per sensitivity column); a macro step is 36 of them, accepted or rejected as a whole",
+           "vectors_per_s": V / (ms * 1e-3), "launches_per_pass": 1, "failed_vectors": failed,
+           "macro_steps_per_vector": macro / V, "state_only": {"ms": ms_state, "macro_steps_per_vector": macro_state / V},
+           "parity_of_timed_pass": stiff_golden_parity(gdir, Pn, Y, S),
+           "roofline": B.hbm_roofline("sbm_iex_kernel<stiff50>", 'iex_stiff50', ms, euler, 2 * 8 * 2550,
+                                      "SURVEY.md section 8(d): 40 800 B per step under the state-streaming model (a "
+                                      "streaming integrator reads and writes the augmented state once per implicit-Euler "
+                                      "step); a fraction above 1 says only that a streaming integrator could not run this "
+                                      "fast -- the kernel keeps S in registers and LDS, see roofline_valu_issue")}
+    out["roofline"]["achieved_fp64"] = B.fp64_rate(F, formula, euler / (ms * 1e-3))
+    rv = B.valu_roofline('iex_stiff50', ms, euler)
+    if rv:
+        out["roofline_valu_issue"] = rv
+    # round 2's timed setting beside it: the hand-chosen fixed-step Richardson pair
+    try:
+        fx = run_configs4_fixed(model, gm, dev, reps=reps, cpu=False, setup=(gm5, m5, Pn, P5, t_np, t5, gdir))
+        out["fixed_step_pair"] = {k: fx[k] for k in ("ms", "steps", "value", "parity_of_timed_pass", "setting")}
+        out["speedup_over_fixed_step_pair"] = fx["ms"] / ms
+    except Exception as e:   # noqa: BLE001
+        out["fixed_step_pair"] = {"error": repr(e)[:200]}
+    if cpu:
+        out["cpu_baseline"] = stiff_cpu_legs(gm5, Pn, t_np)
+    return out
+
+
+def stiff_pass_fixed(torch, dev, dm, P5, t5, bufs):
+    """One evaluation of the 4096-vector stiff ensemble with the fixed-step pair (STIFF_FIXED_SETTING)."""
     from sysbio_modeling_amd import _lib, models_zoo
     Yc, Sc, Yf, Sf, st, ns, nw, st2, ns2, nw2 = bufs
     o1 = _lib.make_opts('implicit_midpoint', rtol=1e-10, atol=1e-12, n_steps=4096, t_end=models_zoo.STIFF_T_END, step_mult=1)
@@ -166,27 +343,12 @@ def stiff_pass(torch, dev, dm, P5, t5, bufs):
     return Yf, Sf
 
 
-STIFF_SETTING = "implicit midpoint, 4096 + 8192 fixed steps, Richardson-extrapolated on the device"
-
-
-def run_configs4(model, gm, dev, reps=3, cpu=True):
+def run_configs4_fixed(model, gm, dev, reps=3, cpu=True, setup=None):
+    """configs[4] with round 2's hand-chosen fixed-step pair (kept for comparison and as a profiling workload)."""
     import torch
-    import os
-    from sysbio_modeling_amd import models_zoo
-    from sysbio_modeling_amd.symbolic import zoo_model
-    from sysbio_modeling_amd.model import OdeModel
-    gm5 = zoo_model('stiff50')
-    m5 = OdeModel(gm5.model, gm5.sens_model, gm5.n_vars, gm5.param_order, use_jit=False)
-    m5.enable_jit(model.device_model.ctx)
+    gm5, m5, Pn, P5, t_np, t5, gdir = setup or _stiff_setup(model, dev)
     dm = m5.device_model
-    V = 4096
-    theta5, Pn = models_zoo.stiff_ensemble(V)
-    g = np.load(os.path.join(B.REPO, 'tests', 'golden', 'stiff50_ref.npz'))
-    assert np.array_equal(Pn[:3], g['P'])
-    P5 = torch.from_numpy(Pn).to(dev)
-    t_np = np.concatenate([[0.0], g['t'][g['idx']]])
-    t5 = torch.from_numpy(t_np).to(dev)
-    nt = len(t_np)
+    V, nt = Pn.shape[0], len(t_np)
     f64, i32 = torch.float64, torch.int32
     bufs = (torch.empty((V, nt, 50), dtype=f64, device=dev), torch.empty((V, nt, 50, 50), dtype=f64, device=dev),
             torch.empty((V, nt, 50), dtype=f64, device=dev), torch.empty((V, nt, 50, 50), dtype=f64, device=dev)) + \
@@ -194,48 +356,96 @@ def run_configs4(model, gm, dev, reps=3, cpu=True):
     holder = {}
 
     def go():
-        holder['YS'] = stiff_pass(torch, dev, dm, P5, t5, bufs)
+        holder['YS'] = stiff_pass_fixed(torch, dev, dm, P5, t5, bufs)
     ms = _events(torch, dev, go, reps)
     Yg, Sg = holder['YS']
     steps = int(bufs[5].sum().item()) + int(bufs[8].sum().item())
     newton = int(bufs[6].sum().item()) + int(bufs[9].sum().item())
-    failed = int(((bufs[4] != 0) | (bufs[7] != 0)).sum().item())
-    # parity of the timed pass against the REAL reference's LSODA results (tests/golden/stiff50_ref.npz: 3 vectors)
-    from oracle.tolerances import parity_err
-    ey = parity_err(Yg[:3, 1:].cpu().numpy(), g['Y'])
-    es = parity_err(Sg[:3, 1:].cpu().numpy().reshape(3, nt - 1, 2500), g['S'])
-    out = {"workload": "configs[4]: stiff50 (50 states, 50 sensitivity parameters: 2550 coupled ODEs, rates spanning "
-                       "1e6), 4096 vectors, 16 output times, " + STIFF_SETTING,
-           "ms": ms, "steps": steps, "value": steps / (ms * 1e-3), "unit": "ODE-steps/s",
-           "vectors_per_s": V / (ms * 1e-3), "launches_per_pass": 2, "newton_iterations_per_step": 1.0 + newton / max(steps, 1),
-           "failed_vectors": failed,
-           "parity_of_timed_pass": {"vectors_checked": 3, "state_err_in_tolerance_units": ey,
-                                    "sens_err_in_tolerance_units": es,
-                                    "tolerance": "|gpu - ref| <= 1e-8 |ref| + 5e-9 against the real reference "
-                                                 "OdeModel's results (tests/golden/stiff50_ref.npz)"},
+    out = {"workload": "configs[4] with " + STIFF_FIXED_SETTING, "setting": STIFF_FIXED_SETTING,
+           "ms": ms, "steps": steps, "value": steps / (ms * 1e-3), "unit": "ODE-steps/s", "launches_per_pass": 2,
+           "newton_iterations_per_step": 1.0 + newton / max(steps, 1),
+           "failed_vectors": int(((bufs[4] != 0) | (bufs[7] != 0)).sum().item()),
+           "parity_of_timed_pass": stiff_golden_parity(gdir, Pn, Yg, Sg),
            "roofline": B.hbm_roofline("sbm_imid_kernel<stiff50>", 'imid_stiff50', ms, steps, 2 * 8 * 2550,
-                                      "SURVEY.md section 8(d): 40 800 B per step under the state-streaming model; a "
-                                      "fraction above 1 only says that a streaming integrator could not run this "
-                                      "fast -- the kernel is register-resident, see roofline_valu_issue")}
+                                      "40 800 B per implicit-midpoint step under the state-streaming model")}
+    F, formula = B.flops_per_step(gm5, 'implicit_midpoint', evals_per_step=1.0 + newton / max(steps, 1))
+    out["roofline"]["achieved_fp64"] = B.fp64_rate(F, formula, steps / (ms * 1e-3))
     rv = B.valu_roofline('imid_stiff50', ms, steps)
     if rv:
         out["roofline_valu_issue"] = rv
-    if cpu:
-        # LSODA on the 2550-equation system differences (and factors) a dense 2550 x 2550 Jacobian: 45 - 150 s per
-        # vector on one core.  The bounded sample is ONE vector over the first tenth of the time span (the first 100
-        # of the reference's 1000 grid points); the rate is steps per second either way.
-        from oracle import odeint_oracle as oo
-        gm5.c_library()
-        t0 = time.perf_counter()
-        (_, _), info = oo.calc_jacobian(gm5, Pn[3], g['t'][:101], use_c=True, return_states=True, full_output=True)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {
-            "value": int(info['nst'][-1]) / dt, "unit": "ODE-steps/s", "cores": 1, "kind": "port",
-            "sample": "1 vector (#3 of the ensemble) over t in [0, 1] (the first 100 of the 1000 grid points; the whole "
-                      "span takes 45 - 150 s per vector): scipy.integrate.odeint rtol=atol=1e-10, 2550 ODEs, compiled C "
-                      "RHS, Dfun=None as in the reference's default call; %.1f s, %d LSODA steps, %d Jacobian "
-                      "evaluations" % (dt, int(info['nst'][-1]), int(info['nje'][-1]))}
     return out
+
+
+def _silence_fortran_unit6():
+    """ODEPACK writes its warnings ("lsoda-- ...") to Fortran unit 6 = the C-level stdout / stderr of the process; a
+    CPU leg that provokes hundreds of them buries bench.py's own output.  Returns a function that restores the
+    descriptors."""
+    import os
+    import sys
+    sys.stdout.flush()
+    sys.stderr.flush()
+    saved = (os.dup(1), os.dup(2))
+    null = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(null, 1)
+    os.dup2(null, 2)
+    os.close(null)
+
+    def restore():
+        os.dup2(saved[0], 1)
+        os.dup2(saved[1], 2)
+        os.close(saved[0])
+        os.close(saved[1])
+    return restore
+
+
+def stiff_cpu_legs(gm5, Pn, t_np):
+    """CPU legs of configs[4] on one host core, vector #3 of the ensemble:
+      as_reference   the reference's default call -- odeint, Dfun=None: LSODA differences a dense 2550 x 2550 Jacobian --
+                     over t in [0, 1], a tenth of the span (the whole span takes 45 - 150 s per vector);
+      analytic_dfun  the reference's use_jac path (model/ode_model.py:114-120) with the generated analytic Jacobian of the
+                     augmented system as Dfun, over t in [0, 0.1]; the full-span timings of both calls are measured once per
+                     round (scripts/cpu_leg_stiff50.py -> profiles/r03/stiff50_cpu_full_span.json) and quoted from there."""
+    from oracle import odeint_oracle as oo
+    gm5.c_library()
+    p = Pn[3]
+    grid = np.linspace(0.0, 10.0, 1000)
+    restore = _silence_fortran_unit6()
+    try:
+        t0 = time.perf_counter()
+        (_, _), info = oo.calc_jacobian(gm5, p, grid[:101], use_c=True, return_states=True, full_output=True)
+        dt = time.perf_counter() - t0
+        legs = {"value": int(info['nst'][-1]) / dt, "unit": "ODE-steps/s", "cores": 1, "kind": "port",
+                "sample": "1 vector (#3 of the ensemble) over t in [0, 1] (the first 100 of the 1000 grid points): "
+                          "scipy.integrate.odeint rtol=atol=1e-10, 2550 ODEs, compiled C RHS, Dfun=None as in the reference's "
+                          "default call; %.1f s, %d LSODA steps, %d Jacobian evaluations"
+                          % (dt, int(info['nst'][-1]), int(info['nje'][-1])),
+                "seconds": dt, "span_covered": [0.0, float(grid[100])]}
+        # the use_jac path on a shorter span (the Python callback fills a 2550 x 2550 matrix per Jacobian evaluation)
+        jac = gm5.sens_model_jac
+        n_pts = 11
+        t0 = time.perf_counter()
+        (_, _), inf2 = oo.calc_jacobian(gm5, p, grid[:n_pts], use_c=True, return_states=True, full_output=True,
+                                        sens_model_jac=jac)
+        d2 = time.perf_counter() - t0
+        legs["analytic_dfun"] = {
+            "value": int(inf2['nst'][-1]) / d2, "unit": "ODE-steps/s", "cores": 1, "kind": "port", "seconds": d2,
+            "span_covered": [0.0, float(grid[n_pts - 1])],
+            "sample": "the same vector, Dfun = the generated analytic Jacobian of the augmented system "
+                      "(GeneratedModel.sens_model_jac, col_deriv layout: the reference's use_jac path), t in [0, %.2f]: "
+                      "%.1f s, %d LSODA steps, %d Jacobian evaluations" % (grid[n_pts - 1], d2, int(inf2['nst'][-1]),
+                                                                          int(inf2['nje'][-1]))}
+        # the whole span, measured once per round by scripts/cpu_leg_stiff50.py (minutes of one core: not part of a
+        # default bench run) and committed under profiles/
+        import json
+        import os
+        for rnd in ('r03',):
+            fp = os.path.join(B.REPO, 'profiles', rnd, 'stiff50_cpu_full_span.json')
+            if os.path.exists(fp):
+                with open(fp) as fh:
+                    legs["full_span_measured_once"] = json.load(fh)
+    finally:
+        restore()
+    return legs
 
 
 # ---------------------------------------------------------------------------
@@ -329,11 +539,14 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
                 raise _OutOfTime()
             calls[1] += 1
             return po.calc_project_jacobian(x)
+        restore = _silence_fortran_unit6()      # (a stiff trial point makes ODEPACK print hundreds of warnings)
         t0 = time.perf_counter()
         try:
             x, _, info, _, ier = leastsq(res, starts[0], Dfun=jac, full_output=True, maxfev=400)
         except _OutOfTime:
             x, ier = best_x[0], -1       # stopped by the time budget: best point so far
+        finally:
+            restore()
         dt = time.perf_counter() - t0
         t0 = time.perf_counter() + 1e9   # (the cost evaluation below is not part of the budget)
         out["cpu_baseline"] = {
@@ -347,7 +560,17 @@ def run_fit(model, gm, dev, reps=1, cpu=True):
             "distance_to_gpu_optimum_of_same_start": float(np.max(np.abs(x - fit['theta'][0]))),
             "note": "the problem is sloppy (68 parameters, many barely constrained by 512 rows): optima are compared "
                     "by their COST; parameter vectors of equal cost lie far apart along the sloppy directions"}
-        out["speedup_vs_one_core"] = out["fits_per_s"] / out["cpu_baseline"]["value"]
+        cb = out["cpu_baseline"]
+        cb["finished"] = ier in (1, 2, 3, 4)
+        if cb["finished"] and cb["cost"] <= 1.001 * cb["gpu_cost_of_same_start"]:
+            out["speedup_vs_one_core"] = out["fits_per_s"] / cb["value"]
+        else:
+            # a fit cut off by the time budget (or one that stopped at a worse cost) is not a baseline to divide by
+            cb["value"] = None
+            out["speedup_vs_one_core"] = None
+            cb["note_unfinished"] = ("leastsq did not finish inside the budget (or stopped at a higher cost than the GPU fit of "
+                                     "the same start): no rate and no speed-up are reported; seconds per evaluation: %.2f"
+                                     % (dt / max(calls[0] + calls[1], 1)))
     return out
 
 
@@ -493,6 +716,6 @@ def run_dop853(model, gm, dev, reps=3, cpu=True):
             "steps_per_s": steps / (ms * 1e-3), "algorithmic_GBps": steps * B.BYTES_PER_STEP / (ms * 1e-3) / 1e9}
 
 
-RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'fit': run_fit, 'dense': run_dense,
-           'dop853': run_dop853}
+RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'configs4_fixed': run_configs4_fixed,
+           'fit': run_fit, 'dense': run_dense, 'dop853': run_dop853}
 ORDER = ['configs1', 'configs3', 'configs4', 'fit', 'dense']

@@ -24,17 +24,22 @@ import shutil
 import sys
 
 # key -> (workload, kernel-name regex, path of "steps per pass" inside the workload's plain.json, launches per pass)
+# ... and the native module the kernel lives in ('core' = libsbm_hip.so, else the model plugin's name): its build stamp
+# (bench.py's "build" object in plain.json) is stored with the entry, and bench.py prints the entry only while the
+# module it runs carries the same stamp.
 KEYS = {
-    'sens_rowgroup_cascade20_dopri45': ('headline', r'sbm_sens_rowgroup_kernel<.*, 1>', ('headline', 'steps_per_pass'), 1),
-    'state_packed_cascade20_dopri45': ('configs1', r'sbm_state_packed_kernel<.*, 1, ', ('configs1', 'dopri45', 'steps'), 1),
-    'state_packed_cascade20_rk4_fixed_4096': ('configs1', r'sbm_state_packed_kernel<.*, 0, ', ('configs1', 'rk4_fixed_4096', 'steps'), 1),
-    'imid_stiff50': ('configs4', r'sbm_imid', ('configs4', 'steps'), None),
-    'lm_step': ('fit', r'k_lm_step', None, None),
-    'lm_trust_step': ('fit', r'k_lm_trust', None, None),
-    'assemble': ('headline', r'k_assemble', None, 1),
-    'sens_rowgroup_cascade20_dop853': ('dop853', r'sbm_sens_rowgroup_kernel<.*RG2, 5>', ('dop853', 'steps'), 1),
-    'dense20_valu': ('dense', r'sbm_sens_rowlane_kernel', ('dense', 'valu', 'steps'), 1),
-    'dense20_mfma': ('dense', r'sbm_sens_mfma_kernel', ('dense', 'mfma', 'steps'), 1),
+    'sens_rowgroup_cascade20_dopri45': ('headline', r'sbm_sens_rowgroup_kernel<.*, 1>', ('headline', 'steps_per_pass'), 1, 'cascade20'),
+    'state_packed_cascade20_dopri45': ('configs1', r'sbm_state_packed_kernel<.*, 1, ', ('configs1', 'dopri45', 'steps'), 1, 'cascade20'),
+    'state_packed_cascade20_rk4_fixed_4096': ('configs1', r'sbm_state_packed_kernel<.*, 0, ', ('configs1', 'rk4_fixed_4096', 'steps'), 1, 'cascade20'),
+    'iex_stiff50': ('configs4', r'sbm_iex_kernel', ('configs4', 'euler_steps'), 1, 'stiff50'),
+    'imid_stiff50': ('configs4_fixed', r'sbm_imid_kernel', ('configs4_fixed', 'steps'), None, 'stiff50'),
+    'lm_step': ('fit', r'k_lm_step', None, None, 'core'),
+    'lm_trust_step': ('fit', r'k_lm_trust', None, None, 'core'),
+    'lm_update': ('fit', r'k_lm_update', None, None, 'core'),
+    'assemble': ('headline', r'k_assemble', None, 1, 'core'),
+    'sens_rowgroup_cascade20_dop853': ('dop853', r'sbm_sens_rowgroup_kernel<.*RG2, 5>', ('dop853', 'steps'), 1, 'cascade20'),
+    'dense20_valu': ('dense', r'sbm_sens_rowlane_kernel', ('dense', 'valu', 'steps'), 1, 'dense20'),
+    'dense20_mfma': ('dense', r'sbm_sens_mfma_kernel', ('dense', 'mfma', 'steps'), 1, 'dense20'),
 }
 
 
@@ -111,7 +116,7 @@ def main(src, dst):
                         plain = json.load(fh)
             except (OSError, ValueError):
                 continue
-        for key, (kw, rx, steps_path, per_pass) in KEYS.items():
+        for key, (kw, rx, steps_path, per_pass, module) in KEYS.items():
             if kw != w:
                 continue
             hits = [k for k in summary if re.search(rx, k)]
@@ -120,7 +125,8 @@ def main(src, dst):
             # several instantiations may match (e.g. two chunk layouts): take the one with most VALU work
             k = max(hits, key=lambda kk: summary[kk].get('SQ_INSTS_VALU', {}).get('total', 0.0))
             e = summary[k]
-            out = {'kernel': k, 'launch': e['launch'], 'source': os.path.join(dst, '%s_pmc_summary.json' % w)}
+            out = {'kernel': k, 'launch': e['launch'], 'source': os.path.join(dst, '%s_pmc_summary.json' % w),
+                   'module': module, 'build_stamp': ((plain or {}).get('build') or {}).get(module)}
             n_launch = e.get('SQ_INSTS_VALU', e.get('WRITE_SIZE', {'launches': 0}))['launches']
             steps_pass = None
             if plain is not None and steps_path is not None:

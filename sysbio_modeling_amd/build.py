@@ -42,15 +42,19 @@ _hipcc_id = None
 
 
 def _toolchain_id():
-    """What besides the sources decides the bytes of a build: compiler version and target."""
+    """What besides the sources decides the bytes of a build: compiler version and target.  Raises BuildError when
+    hipcc is absent or does not answer -- a failed ``hipcc --version`` must not turn into a DIFFERENT stamp (that
+    would force a silent full rebuild, or a build attempt on a box that only carries prebuilt files)."""
     global _hipcc_id
     if _hipcc_id is None:
+        cc = hipcc_path()
         try:
-            ver = subprocess.run([hipcc_path(), '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                                 text=True).stdout
-        except Exception:   # noqa: BLE001
-            ver = '?'
-        _hipcc_id = hashlib.sha1((ver + OFFLOAD_ARCH).encode()).hexdigest()[:12]
+            proc = subprocess.run([cc, '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        except OSError as e:
+            raise BuildError("%s --version could not be run: %s" % (cc, e))
+        if proc.returncode != 0 or not proc.stdout.strip():
+            raise BuildError("%s --version failed (%d): %s" % (cc, proc.returncode, proc.stdout[-200:]))
+        _hipcc_id = hashlib.sha1((proc.stdout + OFFLOAD_ARCH).encode()).hexdigest()[:12]
     return _hipcc_id
 
 
@@ -81,8 +85,8 @@ def _locked_build(target, cmd_for, sources, what, force=False):
     sees the old file or the new one, never a half-written one.  When hipcc is absent (a box that only runs
     prebuilt files) an existing target is used as it is."""
     import fcntl
-    ref_cmd = cmd_for(target)
     try:
+        ref_cmd = cmd_for(target)         # (resolves hipcc: raises BuildError on a box without it)
         stamp = _stamp_of(ref_cmd, sources)
     except BuildError:
         if os.path.exists(target) and not force:

@@ -128,6 +128,28 @@ class GeneratedModel(object):
         """Jacobian of the augmented system, (n + n*k) square, same contract (generated on first use)."""
         return self._jacobian_callables()[1]
 
+    # -- operation counts (bench.py: achieved fp64 rate, SURVEY.md section 8(d)) -------------------------------
+    def flop_counts(self):
+        """Floating-point operations of the generated code, from the emitter's own CSE'd expressions (every +, -, *, /
+        and power counted as one; a reciprocal the GPU refines with two Newton steps still counts as one division):
+
+          f        the state right-hand side alone (n equations)
+          f_jac    f, the non-zeros of J_y and of J_p together (what one stage of a sensitivity kernel, or one Newton
+                   evaluation of an implicit kernel, evaluates once per trajectory)
+          nnz_jy, nnz_jp, nnz_lu   pattern sizes (nnz_lu: L + U of I - h J_y with fill-in, natural order)
+        """
+        if getattr(self, '_flops', None) is None:
+            import sympy
+            from . import emit_implicit
+            d = self.derived
+
+            def ops(repl, red):
+                return int(sum(sympy.count_ops(e) for _, e in repl) + sum(sympy.count_ops(e) for e in red))
+            pattern, _ = emit_implicit.symbolic_lu(self.spec.n_vars, [(r, c) for r, c, _ in d.jy])
+            self._flops = dict(f=ops(d.repl_f, d.f_only), f_jac=ops(d.repl_all, list(d.f_red) + list(d.jy_red) + list(d.jp_red)),
+                               nnz_jy=len(d.jy), nnz_jp=len(d.jp), nnz_lu=len(pattern))
+        return dict(self._flops)
+
     # -- GPU plugin ---------------------------------------------------------
     def header_path(self):
         from .. import build

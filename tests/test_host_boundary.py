@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libsbm_hip.so does not export %s" % name
         assert name in _lib.SIGNATURES, "python binding has no signature for %s" % name
     assert sorted(_lib.SIGNATURES) == declared
-    assert lib.sbm_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.sbm_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -330,3 +330,36 @@ def test_project_add_remove_and_priors(simple_project):
     assert vec.tolist() == [2.0, -1.0, 3.0]
     assert proj.project_param_vect_to_dict(vec)['Group_1'][('High',)] == -1.0
     assert set(proj.group_experiments(['Deg_Rate']).keys()) == {('High',), ('Low',)}
+
+
+def test_prebuilt_targets_are_used_on_a_box_without_hipcc(tmp_path, monkeypatch):
+    """A box that only carries prebuilt .so files (no hipcc on PATH, HIPCC unset): an existing target is used as it
+    is -- no rebuild attempt, no error -- and a missing one raises BuildError.  A hipcc that does not answer
+    --version must not silently change the stamp either."""
+    from sysbio_modeling_amd import build
+    target = tmp_path / 'libdummy.so'
+    target.write_bytes(b'prebuilt')
+    (tmp_path / 'libdummy.so.stamp').write_text('stamp-of-the-box-that-built-it')
+    src = tmp_path / 'dummy.hip'
+    src.write_text('// nothing')
+    calls = []
+
+    def cmd_for(out):
+        calls.append(out)
+        return [build.hipcc_path(), '-shared', str(src), '-o', out]
+    monkeypatch.setattr(build, '_hipcc_id', None)
+    monkeypatch.setattr(build, 'hipcc_path', lambda: (_ for _ in ()).throw(build.BuildError("hipcc not found")))
+    assert build._locked_build(str(target), cmd_for, [str(src)], 'dummy') == str(target)
+    assert target.read_bytes() == b'prebuilt'
+    with pytest.raises(build.BuildError):
+        build._locked_build(str(tmp_path / 'missing.so'), cmd_for, [str(src)], 'dummy')
+    with pytest.raises(build.BuildError):
+        build._locked_build(str(target), cmd_for, [str(src)], 'dummy', force=True)
+    # a compiler that exists but fails to report its version: same treatment, and nothing is cached
+    fake = tmp_path / 'hipcc'
+    fake.write_text('#!/bin/sh\nexit 3\n')
+    fake.chmod(0o755)
+    monkeypatch.setattr(build, 'hipcc_path', lambda: str(fake))
+    monkeypatch.setattr(build, '_hipcc_id', None)
+    assert build._locked_build(str(target), cmd_for, [str(src)], 'dummy') == str(target)
+    assert build._hipcc_id is None and target.read_bytes() == b'prebuilt'

@@ -1,6 +1,8 @@
 """The implicit-midpoint restatement (oracle/imid_oracle.py) is pinned to the reference integrator
 (SciPy odeint / LSODA through oracle/odeint_oracle.py): second-order convergence towards it, and
 agreement after Richardson extrapolation.  CPU only."""
+import math
+
 import numpy as np
 import pytest
 
@@ -72,3 +74,66 @@ def test_oracle_equals_real_reference_on_stiff50(zoo, golden):
     S4 = g['S'].reshape(3, 16, 50, 50)
     iu = np.triu_indices(50, k=1)
     assert np.abs(S4[:, :, iu[0], iu[1]]).max() < 1e-12
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# extrapolated implicit Euler with local step control (oracle/iex_oracle.py: the scheme of csrc/sbm_implicit_extrap.hpp)
+# ----------------------------------------------------------------------------------------------------------------
+def test_iex_weights_are_polynomial_extrapolation_to_step_zero():
+    """T_KK = sum wH_j T_j extrapolates polynomials of degree < K in h = 1/j to h = 0 exactly; T_K,K-1 those of
+    degree < K - 1 through T_2 .. T_K."""
+    from oracle import iex_oracle
+    for K in (2, 4, 6, 8, 10):
+        wh, we = iex_oracle.weights(K)
+        j = np.arange(1, K + 1, dtype=float)
+        assert abs(wh[1:].sum() - 1.0) < 1e-9 and abs(we[1:].sum()) < 1e-9
+        for deg in range(1, K):
+            assert abs(np.dot(wh[1:], (1.0 / j) ** deg)) < 1e-7 * np.abs(wh).max()
+        wl = wh - we
+        assert wl[1] == 0.0
+        for deg in range(1, K - 1):
+            assert abs(np.dot(wl[1:], (1.0 / j) ** deg)) < 1e-7 * np.abs(wl).max()
+        # the first neglected power is seen by the lower-order combination only: that difference is the estimate
+        assert abs(abs(np.dot(we[1:], (1.0 / j) ** (K - 1))) * math.factorial(K) - 1.0) < 1e-6     # = +-1 / K!
+
+
+def test_iex_reproduces_the_reference_fixture_and_lsoda(zoo, mm):
+    """The scheme against (a) the closed form of the reference's one-state fixture (tests/test_OdeModel.py:31-52:
+    y = k_synt / k_deg (1 - exp(-k_deg t)) and its parameter derivatives) and (b) the reference's odeint call on the
+    Michaelis-Menten fixture; tolerance proportionality: ten times tighter, about ten times closer."""
+    from oracle import iex_oracle
+    gm = zoo('simple')
+    k_deg, k_synt = rc.SIMPLE_PARAMS if hasattr(rc, 'SIMPLE_PARAMS') else (0.001, 0.01)
+    t = np.linspace(10.0, 100.0, 10)
+    Y, S, info = iex_oracle.integrate(gm, np.array([k_deg, k_synt]), t, rtol=1e-9, atol=1e-12, use_c=False)
+    e = np.exp(-k_deg * t)
+    assert info['status'] == 0 and np.allclose(Y[:, 0], k_synt / k_deg * (1 - e), rtol=2e-9)
+    dk_deg = k_synt * (t * e / k_deg - (1 - e) / k_deg ** 2)
+    assert np.allclose(S[:, 0], dk_deg, rtol=1e-8) and np.allclose(S[:, 1], (1 - e) / k_deg, rtol=2e-9)
+    tt = np.linspace(0, 100, 1000)
+    idx = [250, 999]
+    p = rc.MM_PARAMS * np.array([40.0, 30.0, 5.0, 3.0, 20.0])
+    Yr = oo.simulate(mm, p, tt)[idx]
+    Sr = oo.calc_jacobian(mm, p, tt)[idx]
+    errs = []
+    for rtol in (1e-6, 1e-7, 1e-8):
+        Y, S, info = iex_oracle.integrate(mm, p, tt[idx], rtol=rtol, atol=1e-3 * rtol, order=6, use_c=False)
+        assert info['status'] == 0 and info['n_euler'] >= info['n_steps'] * 21
+        errs.append(max(np.max(np.abs(Y - Yr) / (np.abs(Yr) + 1e-3)), np.max(np.abs(S - Sr) / (np.abs(Sr) + 1e-3))))
+    assert errs[0] < 1e-5 and errs[1] < 0.4 * errs[0] and errs[2] < 0.4 * errs[1], errs
+    assert errs[2] < 2e-8
+
+
+def test_iex_on_a_stiff_golden_vector_state_only(zoo, golden):
+    """stiff50 (rates spanning 10^6), one vector of the real reference's golden, state only (the dense numpy solves
+    of the full sensitivity system take minutes here; the GPU tests compare kernel and oracle on it)."""
+    from oracle import iex_oracle
+    from oracle.tolerances import parity_err
+    gm = zoo('stiff50')
+    g, gt = golden('stiff50_ref.npz'), golden('stiff50_tight.npz')
+    t_out = g['t'][g['idx']][:4]
+    Y, _, info = iex_oracle.integrate(gm, g['P'][0], t_out, rtol=3e-9, atol=3e-12, with_sens=False)
+    assert info['status'] == 0 and info['n_steps'] < 60
+    assert parity_err(Y, g['Y'][0][:4]) <= 1.0 and parity_err(Y, gt['Y'][0][:4]) <= 0.5
+    # about three evaluations of f / J_y / J_p per Euler step (quadratically convergent Newton from a cubic predictor)
+    assert 2.0 < info['n_eval'] / info['n_euler'] < 3.6
