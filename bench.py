@@ -569,6 +569,13 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
 
+    if world > 1 and not args.no_extras:
+        # the configuration BASELINE names for the multi-GPU run, sharded the same way (collective: all ranks)
+        try:
+            c3s = bc.run_configs3_sharded(model, gm, dev, world, rank, steps=max(2, args.steps // 2), warmup=1)
+        except Exception as e:   # noqa: BLE001
+            c3s = {"error": repr(e)[:300]}
+        result["configs"] = {"configs3_sharded": c3s}
     if not args.no_extras and rank == 0 and world == 1:
         # BASELINE.json's other configurations, each with its own roofline and CPU leg; then kernel variants
         cfgs = {}
@@ -577,6 +584,12 @@ def main():
                 cfgs[name] = bc.RUNNERS[name](model, gm, dev, reps=3, cpu=not args.no_cpu_baseline)
             except Exception as e:   # noqa: BLE001 -- a failing side config must not cost the headline line
                 cfgs[name] = {"error": repr(e)[:300]}
+        if isinstance(cfgs.get('configs3'), dict) and 'ms' in cfgs['configs3']:
+            c3 = cfgs['configs3']
+            cfgs['configs3_sharded'] = {"n_gpus": 1, "ms": c3['ms'], "steps": c3['steps'], "value": c3['value'],
+                                        "unit": "ODE-steps/s", "scaling": "strong",
+                                        "note": "N = 1: the configs3 figures above (the N > 1 line times the same 1024 x 8 "
+                                                "workload split by vector over the ranks)"}
         result["configs"] = cfgs
         try:
             result["extras"] = bc.variant_extras(model, dev, theta_p, tg, args.rk4_steps)

@@ -142,6 +142,74 @@ def run_configs3(model, gm, dev, reps=3, cpu=True):
     return out
 
 
+def run_configs3_sharded(model, gm, dev, world, rank, steps=5, warmup=1):
+    """BASELINE configs[3] as it is named there -- "8 experiment settings x 1024 vectors, residual + Jacobian assembly,
+    sharded over 8 MI355X via RCCL": the 1024 vectors are split into contiguous blocks, one per rank, every rank
+    evaluates ALL 8 experiments of its block (sysbio_modeling_amd/distributed.py: splitting by experiment would cut
+    through scale-factor groups), no data-path collective, then the all-gather of the per-vector residual norms.
+    STRONG scaling: the total work is fixed.  Collective: every rank of the job must call this."""
+    import torch
+    import torch.distributed as dist
+    from sysbio_modeling_amd import distributed as D
+    # everything that can fail on ONE rank alone happens before the first collective of the timed part, and the ranks
+    # agree on having got through it (a rank that raised would leave the others waiting in the all-gather)
+    err = None
+    try:
+        p4, th4, thetas = _config3(model)
+        V = thetas.shape[0]
+        lo, hi = D.shard_range(V, rank, world)
+        t4 = torch.from_numpy(np.ascontiguousarray(thetas[lo:hi])).to(dev)
+        p4.evaluate_batch(t4, jacobian=True, want=('jacobian',))
+        torch.cuda.synchronize(dev)
+    except Exception as e:   # noqa: BLE001
+        err = repr(e)[:300]
+    if world > 1:
+        flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 0.5:
+            return {"error": err or "another rank failed to set the workload up"}
+    elif err:
+        return {"error": err}
+    holder = {}
+
+    def step():
+        o = p4.evaluate_batch(t4, jacobian=True, want=('jacobian',))
+        holder['o'] = o
+        holder['g'] = D.gather_norms(o['norms'], V)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(max(1, warmup)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    o, g = holder['o'], holder['g']
+    stats = torch.tensor([dt, float(o['n_steps'].sum().item()), float((o['status'] != 0).sum().item())],
+                         dtype=torch.float64, device=dev)
+    mine = bool(torch.equal(g[lo:hi], o['norms'])) and int(g.shape[0]) == V
+    if world > 1:
+        mx, sm = stats.clone(), stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        ok = torch.tensor([1.0 if mine else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        dt, total, failed, mine = float(mx[0]), float(sm[1]), int(sm[2]), bool(ok.item() > 0.5)
+    else:
+        total, failed = float(stats[1]), int(stats[2])
+    ms = 1e3 * dt / steps
+    return {"workload": "configs[3] sharded: 1024 project vectors x 8 experiments (8192 trajectories of 820 ODEs, 512 rows x "
+                        "68 parameters per vector) split by vector over %d rank(s), all-gather of the residual norms" % world,
+            "n_gpus": world, "vectors_per_rank": [D.shard_range(V, r, world)[1] - D.shard_range(V, r, world)[0] for r in range(world)],
+            "ms": ms, "steps": total, "value": total / (ms * 1e-3), "unit": "ODE-steps/s", "scaling": "strong",
+            "failed_vectors": failed, "gathered_norms_match_local_block_on_every_rank": mine}
+
+
 def _oracle_rows(args):
     """one worker of oracle_parity_pool: the assembly oracle (SciPy odeint per experiment + numpy assembly) on its share"""
     experiments, settings, mapping, sf_groups, rows = args

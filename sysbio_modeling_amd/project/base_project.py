@@ -112,6 +112,12 @@ class Project(object):
                 from .observables import compile_observable
                 gm = getattr(self._model, 'generated', None)
                 names = list(gm.spec.variables) if gm is not None else ['y%d' % i for i in range(self._model.n_vars)]
+                if isinstance(mapping_args, (tuple, list)) and len(mapping_args) == 3 and callable(mapping_args[1]):
+                    # the reference's own form (parameters, map_fn, jacobian_map_fn): read off the callbacks once the
+                    # experiments are known (they are run, traced, on an experiment's grid: observables.py)
+                    self._measurement_to_model_map[measure_name] = {'type': 'custom', 'variables': [], 'program': None,
+                                                                    'callbacks': tuple(mapping_args), 'names': names}
+                    continue
                 comp = compile_observable(mapping_args, names)
                 self._measurement_to_model_map[measure_name] = {'type': 'custom', 'variables': list(comp['variables']),
                                                                 'program': comp}
@@ -120,8 +126,27 @@ class Project(object):
                 raise ValueError('Invalid mapping type')
             self._measurement_to_model_map[measure_name] = {'type': mapping_type, 'variables': variables}
 
+    def _resolve_callback_mappings(self):
+        """'custom' mappings given as the reference's callbacks: traced and compiled on first sight of an experiment
+        that carries the measure (observables.trace_callback_observable)."""
+        from .observables import compile_observable, trace_callback_observable
+        for measure_name, m in self._measurement_to_model_map.items():
+            if m['type'] != 'custom' or m.get('program') is not None:
+                continue
+            for experiment in self._experiments:
+                ms = [x for x in experiment.measurements if x.variable_name == measure_name]
+                if not ms:
+                    continue
+                par, fn, jac = m['callbacks']
+                expr = trace_callback_observable(par, fn, jac, m['names'], experiment, ms[0],
+                                                 len(experiment.param_global_vector_idx))
+                comp = compile_observable(expr, m['names'])
+                m['variables'], m['program'] = list(comp['variables']), comp
+                break
+
     def _update_project_settings(self):
         self._project_param_idx, self._n_project_params, self._residuals_per_param = self._set_local_param_idx()
+        self._resolve_callback_mappings()
         self._n_residuals = self._update_n_residuals()
         self._rows = self._build_rows()
         self._drop_device_project()

@@ -55,6 +55,88 @@ def test_tables_and_rejections():
         compile_observable(({}, lambda *a: None, lambda *a: None), NAMES)
 
 
+def _measure_on_grid():
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    tm = np.linspace(10.0, 80.0, 8)
+    m = TimecourseMeasurement('obs', np.ones(8), tm, 0.1 * np.ones(8))
+    return Experiment('e0', [m]), m
+
+
+def test_reference_style_callbacks_are_traced():
+    """('custom', (parameters, map_fn, jacobian_map_fn)) with callbacks written to the reference's contract
+    (project/utils.py:10-89, project/base_project.py:125-128): the observable is read off map_fn by running it once on
+    a traced simulation, jacobian_map_fn is checked numerically against its derivative."""
+    from sysbio_modeling_amd.project.observables import trace_callback_observable
+    exp, m = _measure_on_grid()
+    k = 5
+    x = [sympy.Symbol(nm, real=True) for nm in NAMES]
+    t = sympy.Symbol('t', real=True)
+
+    # a weighted sum, jacobian_map_fn exactly as the reference would call it (model Jacobian only)
+    def wsum(model_sim, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        return par['w'] * model_sim[idx, 4] + (1 - par['w']) * model_sim[idx, 9], model_t[idx]
+
+    def wsum_jac(model_jac, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        return par['w'] * model_jac[idx, 4 * k:5 * k] + (1 - par['w']) * model_jac[idx, 9 * k:10 * k]
+    e = trace_callback_observable({'w': 0.25}, wsum, wsum_jac, NAMES, exp, m, k)
+    assert sympy.simplify(e - (0.25 * x[4] + 0.75 * x[9])) == 0
+
+    # the reference's own 'sum' pair restated (a loop over variable indices, project/utils.py:48-89)
+    def sum_map(model_sim, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        out = np.zeros((len(idx),))
+        for v in par:
+            out = out + model_sim[idx, v]
+        return out, model_t[idx]
+
+    def sum_jac(model_jac, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        out = np.zeros((len(idx), k))
+        for v in par:
+            out += model_jac[idx, v * k:(v + 1) * k]
+        return out
+    assert sympy.simplify(trace_callback_observable([1, 3, 7], sum_map, sum_jac, NAMES, exp, m, k) - (x[1] + x[3] + x[7])) == 0
+
+    # nonlinear, time-dependent; the Jacobian callback takes the simulation as a keyword (an extension: the reference
+    # passes the model Jacobian only)
+    def readout(model_sim, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        a, b = model_sim[idx, 4], model_sim[idx, 9]
+        return a / (a + b) + par * np.sqrt(model_sim[idx, 7]) * np.exp(-model_t[idx] / 50), model_t[idx]
+
+    def readout_jac(model_jac, model_t, experiment, measurement, par, use_experimental_timepoints=True, model_sim=None):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        a, b, c = model_sim[idx, 4], model_sim[idx, 9], model_sim[idx, 7]
+        return ((b / (a + b) ** 2)[:, None] * model_jac[idx, 4 * k:5 * k] - (a / (a + b) ** 2)[:, None] * model_jac[idx, 9 * k:10 * k]
+                + (par * 0.5 / np.sqrt(c) * np.exp(-model_t[idx] / 50))[:, None] * model_jac[idx, 7 * k:8 * k])
+    e = trace_callback_observable(0.7, readout, readout_jac, NAMES, exp, m, k)
+    assert sympy.simplify(e - (x[4] / (x[4] + x[9]) + 0.7 * sympy.sqrt(x[7]) * sympy.exp(-t / 50))) == 0
+    c = compile_observable(e, NAMES)
+    assert c['variables'] == [4, 7, 9]
+    # ... to the reference's contract (no simulation) a nonlinear observable's derivative cannot be expressed: refused
+    with pytest.raises(TypeError, match="not linear"):
+        trace_callback_observable(0.7, readout, lambda J, t_, e_, m_, p_, u_=True: J[:8, :k], NAMES, exp, m, k)
+    # a Jacobian callback that is not the derivative of the map
+    with pytest.raises(ValueError, match="disagrees"):
+        trace_callback_observable({'w': 0.25}, wsum, lambda J, t_, e_, m_, p_, u_=True: sum_jac(J, t_, e_, m_, [4, 9]), NAMES, exp, m, k)
+
+    # not pointwise (a difference of neighbouring grid points), and a numpy function the tracer does not carry
+    def slope(model_sim, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        return model_sim[idx, 4] - model_sim[idx - 1, 4], model_t[idx]
+    with pytest.raises(ObservableError, match="other grid points"):
+        trace_callback_observable(None, slope, None, NAMES, exp, m, k)
+
+    def cummax(model_sim, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        return np.maximum.accumulate(model_sim[:, 4])[idx], model_t[idx]
+    with pytest.raises(ObservableError, match="expression"):
+        trace_callback_observable(None, cummax, None, NAMES, exp, m, k)
+
+
 @pytest.mark.gpu
 def test_custom_observables_in_a_project_against_reference_style_callbacks(gpu_models, zoo):
     """A Project with two 'custom' measures (a ratio of two species with a scale factor; a weighted, time-dependent
@@ -136,7 +218,11 @@ def test_custom_observables_in_a_project_against_reference_style_callbacks(gpu_m
         assert tol_ratio(out['jacobian'][v], Jref, t['jacobian']) <= 1.0
     # the single-vector reference-named methods take the same route
     assert np.array_equal(proj.residuals(thetas[0]), proj.evaluate_batch(thetas[:1])['residuals'][0])
-    # callbacks are refused with a pointer to the expression form
-    with pytest.raises(TypeError, match="expression"):
-        Project(gpu_models('cascade20'), exps(), settings, {'ratio': ('custom', ((4, 9), ratio_map, ratio_jac)),
-                                                           'readout': ('direct', 2), 's19': ('direct', 19)})
+    # the reference's own form -- (parameters, map_fn, jacobian_map_fn): the callbacks the oracle above RUNS are read off
+    # (traced once on the host, project/observables.py) and compiled: the same programs, the same numbers bit for bit
+    proj_cb = Project(gpu_models('cascade20'), exps(), settings,
+                      {'ratio': ('custom', ((4, 9), ratio_map, ratio_jac)),
+                       'readout': ('custom', ({'w': 0.3}, readout_map, readout_jac)), 's19': ('direct', 19)}, sf_groups=['ratio'])
+    out_cb = proj_cb.evaluate_batch(thetas, jacobian=True, want=('jacobian', 'model_jacobian', 'sf_gradient'))
+    for key in ('sims', 'residuals', 'jacobian', 'model_jacobian'):
+        assert np.array_equal(out_cb[key], out[key]), key
