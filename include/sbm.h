@@ -422,6 +422,51 @@ int sbm_lm_trust_step(sbm_ctx* ctx, const double* J_dev, const double* r_dev, do
                       const double* radius_dev, double* lambda_dev, int32_t V, int32_t M, int32_t q,
                       double* delta_dev, double* pred_dev, double* dxnorm_dev, int32_t* status_dev);
 
+/* sbm_lm_trust_step with what a batched fitting loop needs around it folded in (project/fitting.py, since round 3):
+ *   row_scale [M]  nullable  J is used as diag(row_scale) J -- a reference_compat Jacobian is not divided by sigma
+ *                            (squared_loss_function.py:52-53,76), the normal equations want d r / d theta
+ *   skip [V]       nullable  != 0: the vector is left alone (delta = 0, trial = theta, status 2): converged starts
+ *   max_step                 > 0: every component of the step is clipped to +-max_step (exp(theta) stays finite); pred,
+ *                            dxnorm and gtx are then those of the step TAKEN (pred = -g.x - x^T J^T J x / 2)
+ *   theta, trial [V][q]      nullable, together: trial = theta + delta
+ *   gtx [V]        nullable  out: g . delta, the directional derivative of 0.5 |r|^2 along the step (lmder's dirder x |r|^2)
+ * A damped system that fails to factor after an earlier one succeeded leaves the LAST SOLVED step (round 2 returned the
+ * unsolved right-hand side with status 0).  LDS: the q x (q + 1) matrix + a row tile of J that shrinks from 32 to 8 rows
+ * to fit the device's limit (q = 128 fits with 16 rows); a q that does not fit is refused with SBM_E_ARG. */
+int sbm_lm_trust_step_ex(sbm_ctx* ctx, const double* J_dev, const double* r_dev, double* dscale_dev,
+                         const double* radius_dev, double* lambda_dev, int32_t V, int32_t M, int32_t q,
+                         const double* row_scale_dev, const int32_t* skip_dev, double max_step,
+                         const double* theta_dev, double* trial_dev, double* delta_dev, double* pred_dev,
+                         double* dxnorm_dev, double* gtx_dev, int32_t* status_dev);
+
+/* lmder's bookkeeping between two steps (MINPACK lmder.f, the loop around lmpar: what scipy.optimize.leastsq -- the
+ * reference's optimiser, tests/test_Project.py:202-213, 351-357 -- does after every function evaluation), for V starts
+ * in one launch: actual and predicted relative reduction, their ratio, the radius / lambda update (ratio <= 1/4: shrink
+ * by 1/2 or by the parabola-fit factor down to 1/10; ratio >= 3/4 or lambda = 0: Delta = 2 ||D delta||), acceptance
+ * (ratio >= 1e-4 and an integrable trial point) and the convergence tests (info 1: both reductions <= ftol with
+ * ratio <= 2; info 2: Delta <= xtol ||D theta||).
+ *   cost [V]            0.5 |r|^2 at the current points       norms_trial, status_trial [V]   |r|^2 and integration
+ *   pred, dxnorm, gtx, step_status [V]   from sbm_lm_trust_step_ex     status of the trial points (sbm_*_batch)
+ *   theta, dscale [V][q]                 current points, scaling
+ *   iteration, first                     iteration index (recorded in n_iter on convergence); first != 0: lmder's
+ *                                        first-iteration rule Delta = min(Delta, ||D delta||)
+ *   radius, lambda, done, n_iter [V]     in / out            accept [V]  out: 1 = the trial point is taken
+ *   counters [2]                         out: starts still running, trial points accepted
+ *   ratio [V]                            nullable, out (traces)
+ * sbm_lm_accept then copies theta, residuals, Jacobian and cost of the accepted trial points over the current ones. */
+int sbm_lm_update(sbm_ctx* ctx, const double* cost_dev, const double* norms_trial_dev, const int32_t* status_trial_dev,
+                  const double* pred_dev, const double* dxnorm_dev, const double* gtx_dev, const int32_t* step_status_dev,
+                  const double* theta_dev, const double* dscale_dev, int32_t V, int32_t q, double ftol, double xtol,
+                  int32_t iteration, int32_t first, double* radius_dev, double* lambda_dev, int32_t* done_dev,
+                  int32_t* accept_dev, int32_t* n_iter_dev, int32_t* counters_dev, double* ratio_dev);
+int sbm_lm_accept(sbm_ctx* ctx, const int32_t* accept_dev, int32_t V, int32_t M, int32_t q, const double* trial_dev,
+                  const double* r_trial_dev, const double* J_trial_dev, const double* norms_trial_dev, double* theta_dev,
+                  double* r_dev, double* J_dev, double* cost_dev);
+
+/* Accepted steps of every TRAJECTORY of the project's last evaluation of V vectors, [V][E] (sbm_*_batch's n_steps is the
+ * sum over a vector's E trajectories; an integrator budget applies per trajectory).  Device to device, on the stream. */
+int sbm_project_trajectory_steps(sbm_project* project, int32_t V, int32_t* steps_dev);
+
 /* ---- multi-GPU: the one exchange of the path ----------------------------- */
 /* The path shards by parameter vector with no data-path collective; what every
  * rank may want afterwards is everybody's per-vector ||r||^2 (sbm_residuals_batch's

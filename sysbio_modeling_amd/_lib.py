@@ -91,6 +91,12 @@ SIGNATURES = {
     'sbm_allgather_norms': (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     'sbm_lm_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     'sbm_lm_trust_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'sbm_lm_trust_step_ex': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, ctypes.c_double, _vp, _vp,
+                                            _vp, _vp, _vp, _vp, _vp]),
+    'sbm_lm_update': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, ctypes.c_double,
+                                     ctypes.c_double, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'sbm_lm_accept': (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'sbm_project_trajectory_steps': (ctypes.c_int, [_vp, _i32, _vp]),
     'sbm_loss_eval_host': (ctypes.c_int, [_vp, ctypes.POINTER(LossDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -1073,6 +1073,19 @@ extern "C" int sbm_project_set_extrapolation(sbm_project* p, int32_t levels) {
   return 0;
 }
 
+// accepted steps of every trajectory of the project's last evaluation, [V][E] (vector-major), device to device
+extern "C" int sbm_project_trajectory_steps(sbm_project* p, int32_t V, int32_t* steps_dev) {
+  if (!p || !steps_dev) return sbm_fail(SBM_E_ARG, "sbm_project_trajectory_steps: NULL argument");
+  if (V < 0) return sbm_fail(SBM_E_ARG, "sbm_project_trajectory_steps: V < 0");
+  const size_t T = (size_t)V * p->E;
+  if (T == 0) return 0;
+  if (!p->traj_steps.p || p->traj_steps.n < T)
+    return sbm_fail(SBM_E_ARG, "sbm_project_trajectory_steps: the project has not evaluated %d vectors yet", V);
+  SBM_HIP(hipSetDevice(p->model->ctx->device));
+  SBM_HIP(hipMemcpyAsync(steps_dev, p->traj_steps.p, T * sizeof(int32_t), hipMemcpyDeviceToDevice, p->model->ctx->stream));
+  return 0;
+}
+
 static int launch_assemble(const AssembleArgs& g, int V, hipStream_t s, const char* who) {
   const int Gn = g.G > 0 ? g.G : 1;
   const int cw_ = g.q < 256 ? g.q : 256, rpp_ = 256 / cw_;
@@ -1284,10 +1297,27 @@ struct LmArgs {
   double* delta;         // [V][q]
   double* pred;          // [V] predicted decrease of 0.5 |r|^2: -g.delta - 0.5 delta^T (J^T J) delta
   int32_t* status;       // [V] 0 ok, 1 not positive definite / non-finite input (delta = 0)
-  int M, q;
+  int M, q, tile;
 };
 
-constexpr int LM_TILE = 32;   // rows of J staged per pass
+constexpr int LM_TILE = 32;   // rows of J staged per pass (fewer when the q x q matrix leaves less room: lm_lds_bytes)
+
+// LDS of the normal-equation kernels: the q x (q + 1) matrix, `nvec` vectors of q, a row tile of J with the residuals
+// beside it.  The tile shrinks (32, 16, 8 rows) until the total fits what the device gives a workgroup; 0 = no fit.
+static int lm_lds_limit(sbm_ctx* ctx) {
+  int lim = 0;
+  if (hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) != hipSuccess || lim <= 0) lim = 64 * 1024;
+  return lim;
+}
+static size_t lm_lds_bytes(sbm_ctx* ctx, int q, int nvec, int* tile_out) {
+  const size_t ld = (size_t)q + 1;
+  const size_t limit = (size_t)lm_lds_limit(ctx);
+  for (int tile = LM_TILE; tile >= 8; tile /= 2) {
+    const size_t b = sizeof(double) * ((size_t)q * ld + (size_t)nvec * q + (size_t)tile * ld + tile);
+    if (b <= limit) { *tile_out = tile; return b; }
+  }
+  return 0;
+}
 
 __global__ void __launch_bounds__(256) k_lm_step(LmArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lm_smem[];
@@ -1297,8 +1327,9 @@ __global__ void __launch_bounds__(256) k_lm_step(LmArgs a) {
   double* dg = A + (size_t)q * ld;           // [q]      diag(J^T J)
   double* g = dg + q;                        // [q]      J^T r
   double* x = g + q;                         // [q]      right-hand side, then the solution
-  double* T = x + q;                         // [LM_TILE][ld] row tile of J
-  double* rt = T + (size_t)LM_TILE * ld;     // [LM_TILE]
+  const int TILE = a.tile;
+  double* T = x + q;                         // [TILE][ld] row tile of J
+  double* rt = T + (size_t)TILE * ld;        // [TILE]
   __shared__ int s_bad;
   if (tid == 0) s_bad = 0;
   const double* Jv = a.J + (size_t)v * M * q;
@@ -1317,8 +1348,8 @@ __global__ void __launch_bounds__(256) k_lm_step(LmArgs a) {
     oi[n_own] = i; oj[n_own] = e - i * (i + 1) / 2; acc[n_own] = 0.0; ++n_own;
   }
   double gacc = 0.0;   // thread c < q owns g[c]
-  for (int m0 = 0; m0 < M; m0 += LM_TILE) {
-    const int rows = min(LM_TILE, M - m0);
+  for (int m0 = 0; m0 < M; m0 += TILE) {
+    const int rows = min(TILE, M - m0);
     __syncthreads();
     for (int e = tid; e < rows * q; e += 256) {
       const int rr = e / q, c = e - rr * q;
@@ -1414,9 +1445,12 @@ extern "C" int sbm_lm_step(sbm_ctx* ctx, const double* J, const double* r, const
   if (V < 0 || M <= 0 || q <= 0 || q > 128) return sbm_fail(SBM_E_ARG, "sbm_lm_step: bad sizes V=%d M=%d q=%d (q <= 128)", V, M, q);
   if (V == 0) return 0;
   SBM_HIP(hipSetDevice(ctx->device));
-  LmArgs a{J, r, lambda, delta, pred, status, M, q};
   const size_t ld = (size_t)q + 1;
-  const size_t lds = sizeof(double) * (q * ld + 3 * q + LM_TILE * ld + LM_TILE);
+  int tile = 0;
+  const size_t lds = lm_lds_bytes(ctx, q, 3, &tile);
+  if (!lds) return sbm_fail(SBM_E_ARG, "sbm_lm_step: q = %d does not fit the %d KB of LDS of a workgroup", q, lm_lds_limit(ctx) / 1024);
+  LmArgs a{J, r, lambda, delta, pred, status, M, q, tile};
+  (void)ld;
   if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_lm_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_lm_step, dim3(V), dim3(256), lds, ctx->stream, a);
   SBM_HIP(hipGetLastError());
@@ -1445,11 +1479,19 @@ struct LmTrustArgs {
   const double* radius;  // [V]     Delta > 0
   double* lambda;        // [V]     in: the previous parameter (a starting guess), out: the one found
   double* delta;         // [V][q]  out: x
-  double* pred;          // [V]     out: predicted decrease of 0.5 |r|^2 = 0.5 x^T J^T J x + lambda ||D x||^2
+  double* pred;          // [V]     out: predicted decrease of 0.5 |r|^2 = -g.x - 0.5 x^T J^T J x
   double* dxnorm;        // [V]     out: ||D x||
-  int32_t* status;       // [V]     out: 0, or 1: non-finite input / no positive definite system found (x = 0)
-  int M, q;
+  int32_t* status;       // [V]     out: 0, 1: non-finite input / no positive definite system found (x = 0), 2: skipped
+  int M, q, tile;
+  // extended entry point (sbm_lm_trust_step_ex); all nullable / 0
+  const double* row_scale;   // [M]    J is used as diag(row_scale) J (reference_compat Jacobians: 1 / sigma)
+  const int32_t* skip;       // [V]    != 0: leave the vector alone (x = 0, status 2)
+  double max_step;           // > 0: every component of x is clipped to +-max_step; pred, dxnorm, gtx are those of the clipped step
+  double* gtx;               // [V]    out: g . x (the directional derivative of 0.5 |r|^2 along the step)
+  const double* theta;       // [V][q] with `trial`: trial = theta + x
+  double* trial;             // [V][q]
 };
+
 
 // in-place Cholesky of the lower triangle of A (q x q, leading dimension ld) by the whole block; false if a pivot is
 // not positive (the decision is uniform: every thread reads the same pivot)
@@ -1494,17 +1536,26 @@ __device__ __forceinline__ void lm_backward(const double* A, double* x, int q, i
 
 __global__ void __launch_bounds__(256) k_lm_trust(LmTrustArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lm_smem[];
-  const int v = blockIdx.x, tid = threadIdx.x, q = a.q, M = a.M;
+  const int v = blockIdx.x, tid = threadIdx.x, q = a.q, M = a.M, TILE = a.tile;
   const int ld = q + 1;
   double* A = lm_smem;                       // [q][ld]  the damped matrix / its Cholesky factor
   double* D = A + (size_t)q * ld;            // [q]      scaling
   double* g = D + q;                         // [q]      J^T r
   double* x = g + q;                         // [q]      step
   double* w = x + q;                         // [q]      work vector of the Newton correction
-  double* T = w + q;                         // [LM_TILE][ld] row tile of J
-  double* rt = T + (size_t)LM_TILE * ld;     // [LM_TILE]
+  double* xg = w + q;                        // [q]      the last step that came out of a successful factorisation
+  double* T = xg + q;                        // [TILE][ld] row tile of J
+  double* rt = T + (size_t)TILE * ld;        // [TILE]
   __shared__ int s_bad;
   __shared__ double s_red[4];
+  if (a.skip && a.skip[v]) {
+    for (int c = tid; c < q; c += 256) {
+      a.delta[(size_t)v * q + c] = 0.0;
+      if (a.trial && a.theta) a.trial[(size_t)v * q + c] = a.theta[(size_t)v * q + c];
+    }
+    if (tid == 0) { a.pred[v] = 0.0; a.dxnorm[v] = 0.0; a.status[v] = 2; if (a.gtx) a.gtx[v] = 0.0; }
+    return;
+  }
   if (tid == 0) s_bad = 0;
   const double* Jv = a.J + (size_t)v * M * q;
   const double* rv = a.r + (size_t)v * M;
@@ -1520,12 +1571,13 @@ __global__ void __launch_bounds__(256) k_lm_trust(LmTrustArgs a) {
     oi[n_own] = i; oj[n_own] = e - i * (i + 1) / 2; acc[n_own] = 0.0; ++n_own;
   }
   double gacc = 0.0;
-  for (int m0 = 0; m0 < M; m0 += LM_TILE) {
-    const int rows = min(LM_TILE, M - m0);
+  for (int m0 = 0; m0 < M; m0 += TILE) {
+    const int rows = min(TILE, M - m0);
     __syncthreads();
     for (int e = tid; e < rows * q; e += 256) {
       const int rr = e / q, c = e - rr * q;
-      const double val = Jv[(size_t)(m0 + rr) * q + c];
+      double val = Jv[(size_t)(m0 + rr) * q + c];
+      if (a.row_scale) val *= a.row_scale[m0 + rr];
       T[rr * ld + c] = val;
       if (!(fabs(val) < 1.0e300)) s_bad = 1;
     }
@@ -1569,6 +1621,7 @@ __global__ void __launch_bounds__(256) k_lm_trust(LmTrustArgs a) {
   if (!(paru > 0.0)) paru = 2.2e-308 / fmin(Delta, 0.1);
   double parl = 0.0, fp = 0.0, dxn = 0.0;
   bool have = false;
+  double lam_good = 0.0, dxn_good = 0.0;      // ... of the last successful factorisation (its step is parked in xg)
 
   auto solve_with = [&](double par) -> bool {          // A <- chol(J^T J + par D^2); x <- -A^-1 g; dxn, fp
     for (int k = 0; k < n_own; ++k) {
@@ -1581,9 +1634,11 @@ __global__ void __launch_bounds__(256) k_lm_trust(LmTrustArgs a) {
     lm_forward(A, x, q, ld, tid);
     lm_backward(A, x, q, ld, tid);
     double p2 = 0.0;
-    if (tid < q) { const double t = D[tid] * x[tid]; p2 = t * t; }
+    if (tid < q) { const double t = D[tid] * x[tid]; p2 = t * t; xg[tid] = x[tid]; }
     dxn = sqrt(block_sum(p2, s_red));
     fp = dxn - Delta;
+    lam_good = par;
+    dxn_good = dxn;
     return true;
   };
   auto newton_denominator = [&]() -> double {           // || L^-1 (D^2 x / dxn) ||^2 with the current factor
@@ -1602,18 +1657,20 @@ __global__ void __launch_bounds__(256) k_lm_trust(LmTrustArgs a) {
       else { const double den = newton_denominator(); if (den > 0.0) parl = (fp / Delta) / den; }
     }
     if (!have) {
+      bool any = false;                                // a damped system has been solved
       lam = fmin(fmax(lam, parl), paru);
       if (lam == 0.0) lam = (dxn > 0.0) ? gnorm / dxn : 1.0e-3 * paru;
       for (int it = 0; it < 10; ++it) {
         if (lam == 0.0) lam = fmax(2.2e-308, 1.0e-3 * paru);
         const double fp_old = fp;
         if (!solve_with(lam)) {                        // rounding: not positive definite at this damping yet
+          // A is half factored and x holds -g: what counts from here on is the last step that WAS solved for (xg)
           parl = fmax(parl, lam);
           lam = fmax(10.0 * lam, 1.0e-3 * paru);
           if (lam > 1.0e3 * paru) break;               // (only non-finite data gets here)
           continue;
         }
-        have = true;
+        any = true;
         if (fabs(fp) <= 0.1 * Delta || (parl == 0.0 && fp <= fp_old && fp_old < 0.0) || it == 9) break;
         const double den = newton_denominator();
         const double parc = den > 0.0 ? (fp / Delta) / den : 0.0;
@@ -1621,36 +1678,213 @@ __global__ void __launch_bounds__(256) k_lm_trust(LmTrustArgs a) {
         if (fp < 0.0) paru = fmin(paru, lam);
         lam = fmax(parl, lam + parc);
       }
+      // the answer is the last DAMPED system that factored -- never the right-hand side a failed factorisation left
+      // in x, nor the undamped step that was outside the region
+      have = any && lam_good > 0.0;
+      if (have) { lam = lam_good; dxn = dxn_good; }
+      __syncthreads();
+      if (have && tid < q) x[tid] = xg[tid];
+      __syncthreads();
     }
   }
   if (bad || !have) {
-    for (int c = tid; c < q; c += 256) a.delta[(size_t)v * q + c] = 0.0;
-    if (tid == 0) { a.pred[v] = 0.0; a.dxnorm[v] = 0.0; a.status[v] = 1; }
+    for (int c = tid; c < q; c += 256) {
+      a.delta[(size_t)v * q + c] = 0.0;
+      if (a.trial && a.theta) a.trial[(size_t)v * q + c] = a.theta[(size_t)v * q + c];
+    }
+    if (tid == 0) { a.pred[v] = 0.0; a.dxnorm[v] = 0.0; a.status[v] = 1; if (a.gtx) a.gtx[v] = 0.0; }
     return;
   }
-  // predicted decrease of 0.5 |r|^2 under the Gauss-Newton model:  -g.x - 0.5 x^T H x  with  x^T H x = -g.x - lam dxn^2
-  double pp = 0.0;
+  // a step bound per component (exp(theta) has to stay finite): clip, and report the quantities of the step TAKEN
+  bool clipped = false;
+  if (a.max_step > 0.0) {
+    int cl = 0;
+    if (tid < q && fabs(x[tid]) > a.max_step) { x[tid] = copysign(a.max_step, x[tid]); cl = 1; }
+    clipped = __syncthreads_or(cl) != 0;
+  }
+  double gx = 0.0;
+  if (tid < q) gx = g[tid] * x[tid];
+  const double gtx = block_sum(gx, s_red);
+  double tot;
+  if (!clipped) {
+    // predicted decrease of 0.5 |r|^2 under the Gauss-Newton model:  -g.x - 0.5 x^T H x  with  x^T H x = -g.x - lam dxn^2
+    tot = -0.5 * gtx + 0.5 * lam * dxn * dxn;
+  } else {
+    double p2 = 0.0;
+    if (tid < q) { const double t = D[tid] * x[tid]; p2 = t * t; }
+    dxn = sqrt(block_sum(p2, s_red));
+    double xhx = 0.0;                                  // x^T (J^T J) x from the lower triangle in registers
+    for (int k = 0; k < n_own; ++k) xhx += (oi[k] == oj[k] ? 1.0 : 2.0) * acc[k] * x[oi[k]] * x[oj[k]];
+    tot = -gtx - 0.5 * block_sum(xhx, s_red);
+  }
   if (tid < q) {
     a.delta[(size_t)v * q + tid] = x[tid];
-    pp = -0.5 * g[tid] * x[tid];
+    if (a.trial && a.theta) a.trial[(size_t)v * q + tid] = a.theta[(size_t)v * q + tid] + x[tid];
   }
-  const double tot = block_sum(pp, s_red) + 0.5 * lam * dxn * dxn;
-  if (tid == 0) { a.pred[v] = tot; a.dxnorm[v] = dxn; a.lambda[v] = lam; a.status[v] = 0; }
+  if (tid == 0) { a.pred[v] = tot; a.dxnorm[v] = dxn; a.lambda[v] = lam; a.status[v] = 0; if (a.gtx) a.gtx[v] = gtx; }
+}
+
+extern "C" int sbm_lm_trust_step_ex(sbm_ctx* ctx, const double* J, const double* r, double* dscale, const double* radius,
+                                    double* lambda, int32_t V, int32_t M, int32_t q, const double* row_scale,
+                                    const int32_t* skip, double max_step, const double* theta, double* trial, double* delta,
+                                    double* pred, double* dxnorm, double* gtx, int32_t* status) {
+  if (!ctx || !J || !r || !dscale || !radius || !lambda || !delta || !pred || !dxnorm || !status)
+    return sbm_fail(SBM_E_ARG, "sbm_lm_trust_step: NULL argument");
+  if (V < 0 || M <= 0 || q <= 0 || q > 128) return sbm_fail(SBM_E_ARG, "sbm_lm_trust_step: bad sizes V=%d M=%d q=%d (q <= 128)", V, M, q);
+  if ((theta == nullptr) != (trial == nullptr)) return sbm_fail(SBM_E_ARG, "sbm_lm_trust_step_ex: theta and trial go together");
+  if (V == 0) return 0;
+  SBM_HIP(hipSetDevice(ctx->device));
+  int tile = 0;
+  const size_t lds = lm_lds_bytes(ctx, q, 5, &tile);
+  if (!lds) return sbm_fail(SBM_E_ARG, "sbm_lm_trust_step: q = %d does not fit the %d KB of LDS of a workgroup", q, lm_lds_limit(ctx) / 1024);
+  LmTrustArgs a{J, r, dscale, radius, lambda, delta, pred, dxnorm, status, M, q, tile, row_scale, skip, max_step, gtx, theta, trial};
+  if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_lm_trust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_lm_trust, dim3(V), dim3(256), lds, ctx->stream, a);
+  SBM_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" int sbm_lm_trust_step(sbm_ctx* ctx, const double* J, const double* r, double* dscale, const double* radius,
                                  double* lambda, int32_t V, int32_t M, int32_t q, double* delta, double* pred,
                                  double* dxnorm, int32_t* status) {
-  if (!ctx || !J || !r || !dscale || !radius || !lambda || !delta || !pred || !dxnorm || !status)
-    return sbm_fail(SBM_E_ARG, "sbm_lm_trust_step: NULL argument");
-  if (V < 0 || M <= 0 || q <= 0 || q > 128) return sbm_fail(SBM_E_ARG, "sbm_lm_trust_step: bad sizes V=%d M=%d q=%d (q <= 128)", V, M, q);
+  return sbm_lm_trust_step_ex(ctx, J, r, dscale, radius, lambda, V, M, q, nullptr, nullptr, 0.0, nullptr, nullptr, delta, pred,
+                              dxnorm, nullptr, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sbm_lm_update / sbm_lm_accept: lmder's bookkeeping between two trust-region steps, for V starts in two launches
+// (round 2 spelled it as ~70 tensor selects per iteration: 68 000 micro-launches in a 100-iteration fit).
+// ---------------------------------------------------------------------------------------------
+struct LmUpdateArgs {
+  const double* cost;       // [V] 0.5 |r|^2 at the current point (inf: a start that cannot be integrated)
+  const double* norms_t;    // [V] |r|^2 at the trial point
+  const int32_t* status_t;  // [V] integration status of the trial point (non-zero: failed)
+  const double* pred;       // [V] from sbm_lm_trust_step_ex
+  const double* dxnorm;     // [V]
+  const double* gtx;        // [V]
+  const int32_t* st;        // [V] status of the trust step (0 ok, 1 no system solved, 2 skipped)
+  const double* theta;      // [V][q] current point (for ||D theta||)
+  const double* dscale;     // [V][q]
+  double* radius;           // [V] in / out
+  double* lambda;           // [V] in / out
+  int32_t* done;            // [V] in / out: 1 = converged (or never started)
+  int32_t* accept;          // [V] out: 1 = take the trial point
+  int32_t* n_iter;          // [V] in / out: iteration at which the start converged
+  int32_t* counters;        // [2] out: starts still running, trial points accepted (zeroed by the caller's memset)
+  double* ratio_out;        // [V] nullable: actual / predicted reduction (traces)
+  double ftol, xtol;
+  int V, q, iteration, first;
+};
+
+__global__ void __launch_bounds__(256) k_lm_update(LmUpdateArgs a) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= a.V) return;
+  a.accept[v] = 0;
+  if (a.done[v]) return;
+  const double cost = a.cost[v];
+  double cost_t = 0.5 * a.norms_t[v];
+  if (!(cost_t < 1.0e300) || a.status_t[v] != 0) cost_t = __builtin_inf();
+  const int st = a.st[v];
+  double radius = a.radius[v], lam = a.lambda[v];
+  const double dxn = a.dxnorm[v];
+  if (a.first && st == 0) radius = fmin(radius, dxn);          // lmder: on the first iteration Delta = min(Delta, ||D p||)
+  // lmder's quantities, relative to |r|^2 = 2 cost
+  const double safe = cost > 0.0 ? cost : 1.0;
+  const bool not_10x_worse = 0.1 * sqrt(cost_t) < sqrt(cost);   // (false for an infinite trial cost)
+  const double actred = not_10x_worse ? 1.0 - cost_t / safe : -1.0;
+  const double prered = a.pred[v] / safe;
+  const double dirder = a.gtx[v] / (2.0 * safe);               // g . p / |r|^2 (= -(|J p|^2 + lam |D p|^2) / |r|^2 for an unclipped step)
+  const double ratio = prered > 0.0 ? actred / prered : 0.0;
+  if (a.ratio_out) a.ratio_out[v] = ratio;
+  if (st != 0) {
+    // no system could be solved: halve the radius, keep the point
+    a.radius[v] = 0.5 * radius;
+    atomicAdd(a.counters, 1);
+    return;
+  }
+  if (ratio <= 0.25) {
+    double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / ((dirder + 0.5 * actred) != 0.0 ? dirder + 0.5 * actred : -1.0);
+    if (!not_10x_worse || temp < 0.1 || !(temp == temp) || !(fabs(temp) < 1.0e300)) temp = 0.1;
+    radius = temp * fmin(radius, dxn / 0.1);
+    lam = lam / temp;
+  } else if (lam == 0.0 || ratio >= 0.75) {
+    radius = dxn / 0.5;
+    lam = 0.5 * lam;
+  }
+  const bool ok = ratio >= 1.0e-4 && cost_t < 1.0e300;
+  a.accept[v] = ok ? 1 : 0;
+  // lmder's convergence tests (info 1, 2); ||D theta|| at the point the iteration ends on
+  double xn2 = 0.0;
+  for (int c = 0; c < a.q; ++c) {
+    const double t = a.dscale[(size_t)v * a.q + c] * a.theta[(size_t)v * a.q + c];
+    xn2 = fma(t, t, xn2);
+  }
+  const bool conv_f = fabs(actred) <= a.ftol && prered <= a.ftol && 0.5 * ratio <= 1.0;
+  const bool conv_x = radius <= a.xtol * sqrt(xn2);
+  a.radius[v] = radius;
+  a.lambda[v] = lam;
+  if (conv_f || conv_x) {
+    a.done[v] = 1;
+    a.n_iter[v] = a.iteration + 1;
+  } else {
+    atomicAdd(a.counters, 1);
+  }
+  if (ok) atomicAdd(a.counters + 1, 1);
+}
+
+extern "C" int sbm_lm_update(sbm_ctx* ctx, const double* cost, const double* norms_trial, const int32_t* status_trial,
+                             const double* pred, const double* dxnorm, const double* gtx, const int32_t* step_status,
+                             const double* theta, const double* dscale, int32_t V, int32_t q, double ftol, double xtol,
+                             int32_t iteration, int32_t first, double* radius, double* lambda, int32_t* done, int32_t* accept,
+                             int32_t* n_iter, int32_t* counters, double* ratio_out) {
+  if (!ctx || !cost || !norms_trial || !status_trial || !pred || !dxnorm || !gtx || !step_status || !theta || !dscale ||
+      !radius || !lambda || !done || !accept || !n_iter || !counters)
+    return sbm_fail(SBM_E_ARG, "sbm_lm_update: NULL argument");
+  if (V < 0 || q <= 0) return sbm_fail(SBM_E_ARG, "sbm_lm_update: bad sizes V=%d q=%d", V, q);
+  SBM_HIP(hipSetDevice(ctx->device));
+  SBM_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(int32_t), ctx->stream));
+  if (V == 0) return 0;
+  LmUpdateArgs a{cost, norms_trial, status_trial, pred, dxnorm, gtx, step_status, theta, dscale, radius, lambda, done, accept,
+                 n_iter, counters, ratio_out, ftol, xtol, V, q, iteration, first};
+  hipLaunchKernelGGL(k_lm_update, dim3((V + 255) / 256), dim3(256), 0, ctx->stream, a);
+  SBM_HIP(hipGetLastError());
+  return 0;
+}
+
+// accepted trial points become the current ones: theta, residuals, Jacobian (scaled by row_scale if given), cost
+__global__ void __launch_bounds__(256) k_lm_accept(const int32_t* __restrict__ accept, int q, int M, const double* __restrict__ trial,
+                                                   const double* __restrict__ r_t, const double* __restrict__ J_t,
+                                                   const double* __restrict__ norms_t, double* __restrict__ theta,
+                                                   double* __restrict__ r, double* __restrict__ J, double* __restrict__ cost) {
+  const int v = blockIdx.x;
+  if (!accept[v]) return;
+  const size_t nJ = (size_t)M * q;
+  const double2* src = reinterpret_cast<const double2*>(J_t + (size_t)v * nJ);
+  double2* dst = reinterpret_cast<double2*>(J + (size_t)v * nJ);
+  if ((nJ & 1) == 0 && ((((size_t)v * nJ) & 1) == 0)) {
+    for (size_t e = threadIdx.x + (size_t)blockIdx.y * blockDim.x; e < nJ / 2; e += (size_t)blockDim.x * gridDim.y) dst[e] = src[e];
+  } else {
+    for (size_t e = threadIdx.x + (size_t)blockIdx.y * blockDim.x; e < nJ; e += (size_t)blockDim.x * gridDim.y)
+      J[(size_t)v * nJ + e] = J_t[(size_t)v * nJ + e];
+  }
+  if (blockIdx.y == 0) {
+    for (int e = threadIdx.x; e < M; e += blockDim.x) r[(size_t)v * M + e] = r_t[(size_t)v * M + e];
+    for (int e = threadIdx.x; e < q; e += blockDim.x) theta[(size_t)v * q + e] = trial[(size_t)v * q + e];
+    if (threadIdx.x == 0) cost[v] = 0.5 * norms_t[v];
+  }
+}
+
+extern "C" int sbm_lm_accept(sbm_ctx* ctx, const int32_t* accept, int32_t V, int32_t M, int32_t q, const double* trial,
+                             const double* r_trial, const double* J_trial, const double* norms_trial, double* theta,
+                             double* r, double* J, double* cost) {
+  if (!ctx || !accept || !trial || !r_trial || !J_trial || !norms_trial || !theta || !r || !J || !cost)
+    return sbm_fail(SBM_E_ARG, "sbm_lm_accept: NULL argument");
+  if (V < 0 || M <= 0 || q <= 0) return sbm_fail(SBM_E_ARG, "sbm_lm_accept: bad sizes V=%d M=%d q=%d", V, M, q);
   if (V == 0) return 0;
   SBM_HIP(hipSetDevice(ctx->device));
-  LmTrustArgs a{J, r, dscale, radius, lambda, delta, pred, dxnorm, status, M, q};
-  const size_t ld = (size_t)q + 1;
-  const size_t lds = sizeof(double) * (q * ld + 4 * q + LM_TILE * ld + LM_TILE);
-  if (lds > 64 * 1024) SBM_HIP(hipFuncSetAttribute((const void*)k_lm_trust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_lm_trust, dim3(V), dim3(256), lds, ctx->stream, a);
+  const int ny = (int)(((size_t)M * q / 2 + 256 * 8 - 1) / (256 * 8));       // ~8 double2 per thread
+  hipLaunchKernelGGL(k_lm_accept, dim3(V, ny < 1 ? 1 : (ny > 64 ? 64 : ny)), dim3(256), 0, ctx->stream, accept, q, M, trial, r_trial,
+                     J_trial, norms_trial, theta, r, J, cost);
   SBM_HIP(hipGetLastError());
   return 0;
 }

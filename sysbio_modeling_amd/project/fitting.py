@@ -16,19 +16,41 @@ import numpy as np
 from .. import _lib
 
 
-def _trial_budget(project, th, integrator_overrides):
-    """Step budget of the TRIAL integrations when the caller named none: five times what the starting points need (at
-    least 2000 attempts), with the early exit (negative ``max_steps``, include/sbm.h).  One launch lasts as long as its
-    slowest trajectory, and an optimiser free to wander along unconstrained parameter directions finds regions where
-    the model is stiff and a trajectory takes 20 times the usual steps: such a trial point is worth rejecting by its
-    price alone -- the trust region then shrinks away from it.  (Measured on the sloppy configs[3] project, 256 starts
-    x 100 iterations of the trust-region algorithm: 4.4 s with a budget of 20 000 attempts, 1.7 s with 5 000, same costs.)"""
+def _trial_budget(project, th, integrator_overrides, n_steps_sum=None, status=None):
+    """Step budget of the TRIAL integrations when the caller named none: five times what the slowest TRAJECTORY of the
+    starting points needs (at least 2000 attempts), with the early exit (negative ``max_steps``, include/sbm.h).  One
+    launch lasts as long as its slowest trajectory, and an optimiser free to wander along unconstrained parameter
+    directions finds regions where the model is stiff and a trajectory takes 20 times the usual steps: such a trial point
+    is worth rejecting by its price alone -- the trust region then shrinks away from it.  (Measured on the sloppy
+    configs[3] project, 256 starts x 100 iterations of the trust-region algorithm: 4.4 s with a budget of 20 000 attempts,
+    1.7 s with 5 000, same costs.)
+
+    The budget is per trajectory and so is the count it is derived from (``sbm_project_trajectory_steps``: round 2
+    divided a vector's SUM over its experiments by their number -- with one slow experiment among eight the starts
+    themselves ran out of budget).  The STARTING points are integrated with the caller's / the model's own budget
+    before this is called (``n_steps_sum`` / ``status`` of that evaluation, if the caller has them); only trial points
+    get the derived one.  Returns the budget set (None if the caller named one)."""
+    import torch
     if 'max_steps' in integrator_overrides:
-        return
-    out = project.evaluate_batch(th, want=('n_steps',), **integrator_overrides)
-    # ('n_steps' is the SUM over a vector's trajectories, one per experiment)
-    typical = float(out['n_steps'].max()) / max(1, len(project._experiments)) if out['n_steps'].numel() else 0.0
-    integrator_overrides['max_steps'] = -max(2000, int(5.0 * typical))
+        return None
+    if n_steps_sum is None:
+        out = project.evaluate_batch(th, want=('n_steps',), **integrator_overrides)
+        n_steps_sum, status = out['n_steps'], out['status']
+    V = int(th.shape[0])
+    E = max(1, len(project._experiments))
+    worst = 0
+    try:
+        per = torch.empty((V, E), dtype=torch.int32, device=th.device)
+        _lib.check(_lib.load_library().sbm_project_trajectory_steps(project._device(), V, _lib.dev_ptr(per)),
+                   'sbm_project_trajectory_steps')
+        ok = (status == 0) if status is not None else torch.ones((V,), dtype=torch.bool, device=th.device)
+        if bool(ok.any()):
+            worst = int(per[ok].max())
+    except _lib.SbmError:
+        worst = int(n_steps_sum.max()) if n_steps_sum.numel() else 0      # (an upper bound of every trajectory's count)
+    budget = -max(2000, int(5.0 * worst))
+    integrator_overrides['max_steps'] = budget
+    return budget
 
 
 def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambda_up=4.0, lambda_down=3.0,
@@ -74,11 +96,18 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     damping, relative decrease and largest step component (costs a device synchronisation per iteration).
     """
     import torch
-    if algorithm in ('trust_region', 'lmder', 'minpack'):
-        return _trust_region_batch(project, thetas0, max_iter=max_iter, ftol=ftol, xtol=xtol, factor=factor, trace=trace,
-                                   lazy_jacobian=lazy_jacobian, max_step=max_step, **integrator_overrides)
+    if algorithm in ('trust_region', 'lmder', 'minpack', 'trust_region_torch'):
+        # the loop's bookkeeping in two device launches per iteration (sbm_lm_update / sbm_lm_accept) whenever the
+        # integration is ONE device call; the control loops of _control.py (method='auto', 'implicit_romberg') and
+        # algorithm='trust_region_torch' (round 2's spelling in tensor selects, kept as the cross-check) take the other
+        from .. import _control
+        o = project._options(**integrator_overrides)
+        one_call = str(o.get('method', 'dopri45')).lower() not in _control.IMPLICIT_CONTROLLED + _control.AUTO
+        fn = _trust_region_fused if (one_call and algorithm != 'trust_region_torch') else _trust_region_batch
+        return fn(project, thetas0, max_iter=max_iter, ftol=ftol, xtol=xtol, factor=factor, trace=trace,
+                  lazy_jacobian=lazy_jacobian, max_step=max_step, **integrator_overrides)
     if algorithm != 'marquardt':
-        raise ValueError("fit_batch: unknown algorithm %r ('marquardt' or 'trust_region')" % (algorithm,))
+        raise ValueError("fit_batch: unknown algorithm %r ('marquardt', 'trust_region' or 'trust_region_torch')" % (algorithm,))
     if lazy_jacobian == 'auto':
         lazy_jacobian = len(thetas0) * max(1, len(project._experiments)) >= 8192
     if project.reference_compat and project.n_total_rows != project.n_project_residuals:
@@ -88,7 +117,6 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     ctx = project._model.device_model.ctx      # the context (device, stream) the project's model lives on
     th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
     th = th.clone()
-    _trial_budget(project, th, integrator_overrides)
     dev = th.device
     V, q = th.shape
     f64, i32 = torch.float64, torch.int32
@@ -99,8 +127,11 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
         a = project.descriptor_arrays()
         inv_sigma = torch.from_numpy(1.0 / a['row_sigma']).to(dev)
 
+    last = {}
+
     def evaluate(t):
         out = project.evaluate_batch(t, jacobian=True, want=want, **integrator_overrides)
+        last['n_steps'], last['status'] = out['n_steps'], out['status']
         J = out['jacobian']
         if inv_sigma is not None:
             J = J * inv_sigma[None, :, None]
@@ -108,7 +139,8 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
         cost = torch.where(torch.isfinite(cost) & (out['status'] == 0), cost, torch.full_like(cost, float('inf')))
         return out['residuals'], J, cost
 
-    r, J, cost = evaluate(th)
+    r, J, cost = evaluate(th)            # the starting points: the caller's / the model's own step budget
+    _trial_budget(project, th, integrator_overrides, n_steps_sum=last['n_steps'], status=last['status'])
     M = r.shape[1]
     lam = torch.full((V,), float(lambda0), dtype=f64, device=dev)
     delta = torch.empty((V, q), dtype=f64, device=dev)
@@ -212,7 +244,6 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
     ctx = project._model.device_model.ctx
     th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
     th = th.clone()
-    _trial_budget(project, th, integrator_overrides)
     dev = th.device
     V, q = th.shape
     f64, i32 = torch.float64, torch.int32
@@ -220,8 +251,11 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
     if project.reference_compat:
         inv_sigma = torch.from_numpy(1.0 / project.descriptor_arrays()['row_sigma']).to(dev)
 
+    last = {}
+
     def evaluate(t):
         out = project.evaluate_batch(t, jacobian=True, want=('jacobian',), **integrator_overrides)
+        last['n_steps'], last['status'] = out['n_steps'], out['status']
         J = out['jacobian']
         if inv_sigma is not None:
             J = J * inv_sigma[None, :, None]
@@ -234,7 +268,12 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         c = 0.5 * out['norms']
         return torch.where(torch.isfinite(c) & (out['status'] == 0), c, torch.full_like(c, float('inf')))
 
-    r, J, cost = evaluate(th)
+    r, J, cost = evaluate(th)            # the starting points: the caller's / the model's own step budget
+    if not bool(torch.isfinite(cost).all()):
+        import warnings
+        warnings.warn("fit_batch: %d of %d starting points could not be integrated; they are returned as they came"
+                      % (int((~torch.isfinite(cost)).sum()), V))
+    _trial_budget(project, th, integrator_overrides, n_steps_sum=last['n_steps'], status=last['status'])
     M = r.shape[1]
     done = ~torch.isfinite(cost)
     dscale = torch.zeros((V, q), dtype=f64, device=dev)
@@ -260,10 +299,19 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
             radius = torch.where(xn > 0, factor * xn, torch.full_like(xn, float(factor)))
         _lib.check(lib.sbm_lm_trust_step(ctx.handle, p(Jc), p(rc), p(dscale), p(radius), p(lam), V, M, q, p(delta), p(pred),
                                          p(dxnorm), p(st)), 'sbm_lm_trust_step')
-        if first:
-            radius = torch.minimum(radius, dxnorm)          # lmder: on the first iteration, Delta = min(Delta, ||D p||)
-            first = False
         step = delta.clamp(-max_step, max_step)
+        clipped = (step != delta).any(dim=1)
+        if bool(clipped.any()):
+            # the quantities of the step TAKEN (round 2 judged the clipped step by the unclipped one's prediction):
+            # pred = -g.x - x^T J^T J x / 2, ||D x||
+            Jx = torch.einsum('vmq,vq->vm', Jc, step)
+            gx = torch.einsum('vm,vm->v', rc, Jx)
+            pred = torch.where(clipped, -gx - 0.5 * (Jx * Jx).sum(dim=1), pred)
+            dxnorm = torch.where(clipped, (dscale * step).norm(dim=1), dxnorm)
+        if first:
+            # lmder: on the first iteration, Delta = min(Delta, ||D p||) -- of the step taken (the clipped one)
+            radius = torch.where(st == 0, torch.minimum(radius, dxnorm), radius)
+            first = False
         trial = torch.where(done[:, None], th, th + step)
         if lazy_jacobian:
             cost_t = cost_only(trial)
@@ -276,8 +324,8 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         actred = torch.where(0.1 * torch.sqrt(cost_t) < torch.sqrt(cost), 1.0 - cost_t / safe_cost, -torch.ones_like(cost))
         actred = torch.where(torch.isfinite(cost_t), actred, -torch.ones_like(cost))
         prered = pred / safe_cost
-        lam_dx2 = lam * dxnorm * dxnorm / (2.0 * safe_cost)          # lam |D p|^2 / |r|^2
-        dirder = -(prered - lam_dx2)                                  # -(|J p|^2 / |r|^2 + lam |D p|^2 / |r|^2)
+        # dirder = g . p / |r|^2  (= -(|J p|^2 + lam |D p|^2) / |r|^2 for an unclipped step: lmder's expression)
+        dirder = torch.einsum('vm,vm->v', rc, torch.einsum('vmq,vq->vm', Jc, step)) / (2.0 * safe_cost)
         ratio = torch.where(prered > 0, actred / torch.where(prered > 0, prered, torch.ones_like(prered)), torch.zeros_like(prered))
         # radius update
         shrink = ratio <= 0.25
@@ -294,6 +342,7 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         lam = torch.where(done | (st != 0), lam, new_lam)
         ok = usable & (ratio >= 1.0e-4) & torch.isfinite(cost_t)
         cost_prev = cost
+        th_before = th.clone() if lazy_jacobian else th
         if lazy_jacobian:
             sel = torch.nonzero(ok).flatten()
             ok = torch.zeros_like(ok)
@@ -314,8 +363,8 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
             J = torch.where(ok[:, None, None], J_t, J)
             cost = torch.where(ok, cost_t, cost)
             n_jac += V
-        # lmder's convergence tests (info 1, 2)
-        xnorm = (dscale * th).norm(dim=1)
+        # lmder's convergence tests (info 1, 2); ||D theta|| of the point the iteration started from, as sbm_lm_update has it
+        xnorm = (dscale * th_before).norm(dim=1)
         conv_f = usable & (actred.abs() <= ftol) & (prered <= ftol) & (0.5 * ratio <= 1.0)
         conv_x = usable & (radius <= xtol * xnorm)
         newly = (conv_f | conv_x) & ~done
@@ -331,4 +380,130 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
             break
     return {'theta': th.cpu().numpy(), 'cost': cost.cpu().numpy(), 'n_iter': n_iter.cpu().numpy(),
             'converged': (done & torch.isfinite(cost)).cpu().numpy(), 'n_evaluations': n_eval,
+            'n_jacobian_evaluations': n_jac, **({'history': history} if trace else {})}
+
+
+def _trust_region_fused(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.49012e-8, factor=100.0, trace=False,
+                        lazy_jacobian='auto', max_step=2.0, **integrator_overrides):
+    """`_trust_region_batch` with the bookkeeping on the device: per iteration ONE ``sbm_lm_trust_step_ex`` (lmpar, the
+    clipped step and the trial point), the integration of the trial points (``sbm_jacobian_batch`` /
+    ``sbm_residuals_batch`` into preallocated buffers), ONE ``sbm_lm_update`` (lmder's ratio / radius / acceptance /
+    convergence logic) and ONE ``sbm_lm_accept`` (the accepted points' theta, r, J, cost) -- about eight launches and one
+    4-byte read-back where round 2's loop issued ~70 tensor selects (68 000 micro-launches in a 100-iteration fit,
+    profiles/r02/fit_kernel_stats.csv).  Same algorithm, same numbers up to the order of a few sums."""
+    import ctypes
+    import warnings
+    import torch
+    if project.reference_compat and project.n_total_rows != project.n_project_residuals:
+        raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
+                         "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
+    if lazy_jacobian == 'auto':
+        lazy_jacobian = len(thetas0) * max(1, len(project._experiments)) >= 8192
+    lib = _lib.load_library()
+    ctx = project._model.device_model.ctx
+    th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
+    th = th.clone()
+    dev = th.device
+    V, q = th.shape
+    proj = project._device()
+    R, M = project._n_residuals, project.n_total_rows
+    G = len(project._loss_function.groups) if hasattr(project._loss_function, 'groups') else 0
+    f64, i32 = torch.float64, torch.int32
+    p = _lib.dev_ptr
+
+    def buffers(n, with_J=True):
+        b = dict(sims=torch.empty((n, R), dtype=f64, device=dev), r=torch.empty((n, M), dtype=f64, device=dev),
+                 sf=torch.empty((n, max(G, 1)), dtype=f64, device=dev), norms=torch.empty((n,), dtype=f64, device=dev),
+                 status=torch.empty((n,), dtype=i32, device=dev), nsteps=torch.empty((n,), dtype=i32, device=dev))
+        if with_J:
+            b['J'] = torch.empty((n, M, q), dtype=f64, device=dev)
+        return b
+
+    def integrate(theta_t, opts, b, jac):
+        n = theta_t.shape[0]
+        if jac:
+            _lib.check(lib.sbm_jacobian_batch(proj, p(theta_t), n, ctypes.byref(opts), p(b['sims']), p(b['r']), p(b['J']), None,
+                                              p(b['sf']) if G else None, None, p(b['norms']), None, p(b['status']),
+                                              p(b['nsteps'])), 'sbm_jacobian_batch')
+        else:
+            _lib.check(lib.sbm_residuals_batch(proj, p(theta_t), n, ctypes.byref(opts), p(b['sims']), p(b['r']),
+                                               p(b['sf']) if G else None, p(b['norms']), p(b['status']), p(b['nsteps'])),
+                       'sbm_residuals_batch')
+
+    cur, tr = buffers(V), buffers(V)
+    integrate(th, project._opts(**integrator_overrides), cur, True)      # the starts: the caller's / the model's own budget
+    cost = torch.where(torch.isfinite(cur['norms']) & (cur['status'] == 0), 0.5 * cur['norms'],
+                       torch.full_like(cur['norms'], float('inf')))
+    bad = ~torch.isfinite(cost)
+    if bool(bad.any()):
+        warnings.warn("fit_batch: %d of %d starting points could not be integrated; they are returned as they came"
+                      % (int(bad.sum()), V))
+        cur['J'][bad] = 0.0
+        cur['r'][bad] = 0.0
+    _trial_budget(project, th, integrator_overrides, n_steps_sum=cur['nsteps'], status=cur['status'])
+    opts_t = project._opts(**integrator_overrides)
+    row_scale = None
+    if project.reference_compat:
+        row_scale = torch.from_numpy(1.0 / project.descriptor_arrays()['row_sigma']).to(dev).contiguous()
+    done = bad.to(i32)
+    dscale = torch.zeros((V, q), dtype=f64, device=dev)
+    lam = torch.zeros((V,), dtype=f64, device=dev)
+    # lmder: D from the first Jacobian, Delta = factor * ||D theta|| (factor itself where that is zero)
+    Js = cur['J'] if row_scale is None else cur['J'] * row_scale[None, :, None]
+    col = torch.sqrt((Js * Js).sum(dim=1))
+    del Js
+    xn = (torch.where(col > 0, col, torch.ones_like(col)) * th).norm(dim=1)
+    radius = torch.where(xn > 0, factor * xn, torch.full_like(xn, float(factor))).contiguous()
+    delta = torch.empty((V, q), dtype=f64, device=dev)
+    trial = torch.empty((V, q), dtype=f64, device=dev)
+    pred, dxnorm, gtx = (torch.empty((V,), dtype=f64, device=dev) for _ in range(3))
+    ratio = torch.empty((V,), dtype=f64, device=dev) if trace else None
+    st = torch.empty((V,), dtype=i32, device=dev)
+    accept = torch.zeros((V,), dtype=i32, device=dev)
+    n_iter = torch.full((V,), int(max_iter), dtype=i32, device=dev)
+    counters = torch.zeros((2,), dtype=i32, device=dev)
+    n_eval, n_jac = V, V
+    history = []
+    for it in range(max_iter):
+        _lib.check(lib.sbm_lm_trust_step_ex(ctx.handle, p(cur['J']), p(cur['r']), p(dscale), p(radius), p(lam), V, M, q,
+                                            p(row_scale), p(done), float(max_step), p(th), p(trial), p(delta), p(pred),
+                                            p(dxnorm), p(gtx), p(st)), 'sbm_lm_trust_step_ex')
+        integrate(trial, opts_t, tr, not lazy_jacobian)
+        n_eval += V
+        cost_prev = cost.clone() if trace else None
+        _lib.check(lib.sbm_lm_update(ctx.handle, p(cost), p(tr['norms']), p(tr['status']), p(pred), p(dxnorm), p(gtx), p(st),
+                                     p(th), p(dscale), V, q, float(ftol), float(xtol), it, 1 if it == 0 else 0, p(radius),
+                                     p(lam), p(done), p(accept), p(n_iter), p(counters), p(ratio)), 'sbm_lm_update')
+        if lazy_jacobian:
+            # MINPACK's economy: the state + sensitivity system only at the trial points that were accepted
+            sel = torch.nonzero(accept).flatten()
+            if sel.numel():
+                sub = buffers(int(sel.numel()))
+                integrate(trial[sel].contiguous(), opts_t, sub, True)
+                n_jac += int(sel.numel())
+                good = torch.isfinite(sub['norms']) & (sub['status'] == 0)
+                accept[sel[~good]] = 0
+                tr['r'][sel] = sub['r']
+                tr['norms'][sel] = sub['norms']
+                if 'J' not in tr:
+                    tr['J'] = torch.empty((V, M, q), dtype=f64, device=dev)
+                tr['J'][sel] = sub['J']
+            elif 'J' not in tr:
+                tr['J'] = torch.empty((V, M, q), dtype=f64, device=dev)
+        else:
+            n_jac += V
+        _lib.check(lib.sbm_lm_accept(ctx.handle, p(accept), V, M, q, p(trial), p(tr['r']), p(tr['J']), p(tr['norms']), p(th),
+                                     p(cur['r']), p(cur['J']), p(cost)), 'sbm_lm_accept')
+        live, n_acc = (int(x) for x in counters.cpu())          # (the one read-back of the iteration)
+        if trace:
+            running = done == 0
+            md = lambda t: float(t[running].median()) if bool(running.any()) else 0.0     # noqa: E731
+            history.append(dict(iteration=it, accepted=n_acc, live=live, cost_median=float(cost.median()),
+                                lambda_median=md(lam), radius_median=md(radius), ratio_median=md(ratio),
+                                rel_decrease_median=md((cost_prev - cost) / cost_prev)))
+        if live == 0:
+            break
+    torch.cuda.synchronize(dev)
+    return {'theta': th.cpu().numpy(), 'cost': cost.cpu().numpy(), 'n_iter': n_iter.cpu().numpy().astype(np.int64),
+            'converged': ((done != 0) & torch.isfinite(cost)).cpu().numpy(), 'n_evaluations': n_eval,
             'n_jacobian_evaluations': n_jac, **({'history': history} if trace else {})}
