@@ -90,7 +90,7 @@ typedef struct sbm_integrator_opts {
   int32_t method;    /* SBM_RK4_FIXED | SBM_DOPRI45 | SBM_DOP853 | SBM_IMPLICIT_MIDPOINT[_GRADED] | SBM_IMPLICIT_ADAPTIVE | SBM_IMPLICIT_EXTRAP */
   int32_t max_steps; /* per trajectory, accepted + rejected; 0 -> 1000000.  DOPRI45, negative: a budget of
                       * (and DOP853) |max_steps| with an early exit (status SBM_MAX_STEPS at once) for a trajectory whose
-                      * current step size would need more than four budgets for the remaining time span --
+                      * current step size would need more than 1.5 x what is left of the budget for the remaining time span --
                       * checked every 256 attempts from the 512th on, and only while the step size has stopped
                       * growing from one check to the next: the explicit method on a stiff system */
   double rtol;       /* DOPRI45, IMPLICIT_ADAPTIVE: relative tolerance; IMPLICIT_MIDPOINT: Newton tolerance */

@@ -302,7 +302,9 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
   using namespace dp;
   const double rtol = o.rtol, atol = o.atol;
   // max_steps < 0: a budget of |max_steps| attempts with an early exit -- a trajectory whose CURRENT step size
-  // would need more than four budgets for the rest of the time span gives up at once (checked every 256
+  // would need more than one and a half times what is LEFT of the budget for the rest of the time span gives up at
+  // once (round 2: four whole budgets -- a trial point of a fit that was going to miss its budget by less than that
+  // ran to the end of it, and one such trajectory sets the duration of the launch; checked every 256
   // attempts from the 512th on, when the controller has settled, and only while the step size has stopped growing
   // from one check to the next).  That is the explicit method on a stiff
   // system, its step size pinned by stability: method='auto' hands such trajectories to the implicit
@@ -370,7 +372,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dopri45(const Sys& sys, double (&z)[Sy
         h_mark = (float)h;
         rej_mark = out.n_rej;
         // (the end of the time span is read again here, in the cold path, rather than kept alive across the step loop)
-        if (!growing && !smooth && (t_out[n_t - 1] - t) > 4.0 * max_steps * h) { out.status = SBM_MAX_STEPS; failed = true; break; }
+        if (!growing && !smooth && (t_out[n_t - 1] - t) > 1.5 * (double)(max_steps - n_try) * h) { out.status = SBM_MAX_STEPS; failed = true; break; }
       }
       ++n_try;
       // clip to land on the output time
@@ -568,7 +570,7 @@ __device__ __forceinline__ SbmTrajOut sbm_dop853(const Sys& sys, double (&z)[Sys
         const bool smooth = out.n_rej - rej_mark < 3;
         h_mark = (float)h;
         rej_mark = out.n_rej;
-        if (!growing && !smooth && (t_out[n_t - 1] - t) > 4.0 * max_steps * h) { out.status = SBM_MAX_STEPS; failed = true; break; }
+        if (!growing && !smooth && (t_out[n_t - 1] - t) > 1.5 * (double)(max_steps - n_try) * h) { out.status = SBM_MAX_STEPS; failed = true; break; }
       }
       ++n_try;
       double hs = h;
@@ -811,9 +813,7 @@ __global__ void __launch_bounds__(64) sbm_sens_kernel(sbm_kernel_args a) {
     }
   };
 
-  SbmTrajOut r;
-  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
-  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+  SbmTrajOut r = sbm_integrate<METHOD>(sys, z, tg, glen, a.opts, store);
 
   if (lane == 0) {
     if (a.status) a.status[traj] = r.status;
@@ -1759,9 +1759,7 @@ __global__ void __launch_bounds__(64) sbm_sens_packed_kernel(sbm_kernel_args a) 
       for (int i = 0; i < NV; ++i) St[((size_t)io * NV + i) * NK + li] = zz[0][i];
     }
   };
-  SbmTrajOut r;
-  if constexpr (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
-  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+  SbmTrajOut r = sbm_integrate<METHOD>(sys, z, tg, glen, a.opts, store);
   if (li == 0 && live) {
     if (a.status) a.status[traj] = r.status;
     if (a.n_steps) a.n_steps[traj] = r.n_acc;
@@ -2013,8 +2011,11 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
   // 16.8; 400 (dense): 65.0 / 21.7 -- the matrix cores win from about 45 % density.  AUTO takes them from there
   // (a static property of the model: a given model always runs the same kernel); SBM_VARIANT_MFMA forces them.
   constexpr bool kMfmaPays = M::NV >= 16 && M::NV <= 64 && (long long)M::NNZ_JY * 100 >= 45LL * M::NV * M::NV;
-  if (kind == SBM_KIND_SENS && a.opts.method != SBM_DOP853 && (a.opts.variant == SBM_VARIANT_MFMA ||
-                                (kMfmaPays && (a.opts.variant == SBM_VARIANT_AUTO || a.opts.variant == SBM_VARIANT_SMALL_BATCH)))) {
+  // (DOP853 keeps twelve stage vectors alive -- on the matrix-core kernel they leave the register file: built, so that a
+  // forced variant answers, but AUTO keeps DOP853 on the row kernels)
+  if (kind == SBM_KIND_SENS && (a.opts.variant == SBM_VARIANT_MFMA ||
+                                (kMfmaPays && a.opts.method != SBM_DOP853 &&
+                                 (a.opts.variant == SBM_VARIANT_AUTO || a.opts.variant == SBM_VARIANT_SMALL_BATCH)))) {
     // models beyond one state row per lane fall through to the scalar kernels
     if constexpr (M::NV <= 64) {
       constexpr int nch = SbmMfmaPlan<M>::NCH;
@@ -2027,6 +2028,7 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
       }
       dim3 grid(a.n_traj, nch), block(64);
       if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_mfma_kernel<M, SBM_DOPRI45>), grid, block, 0, stream, a);
+      else if (a.opts.method == SBM_DOP853) hipLaunchKernelGGL((sbm_sens_mfma_kernel<M, SBM_DOP853>), grid, block, 0, stream, a);
       else hipLaunchKernelGGL((sbm_sens_mfma_kernel<M, SBM_RK4_FIXED>), grid, block, 0, stream, a);
       return (int)hipGetLastError();
     }
@@ -2035,10 +2037,14 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
   if constexpr (M::NV <= 32 && M::NK <= 32 && M::NV * (M::NK + 1) <= 256) {
     constexpr int need = M::NV > M::NK ? M::NV : M::NK;
     constexpr int SEG = need <= 4 ? 4 : (need <= 8 ? 8 : (need <= 16 ? 16 : 32));
-    if (kind == SBM_KIND_SENS && a.opts.method != SBM_DOP853 &&
-        (a.opts.variant == SBM_VARIANT_PACKED || (a.opts.variant == SBM_VARIANT_AUTO && a.n_traj >= 2048))) {
+    // AUTO: small models ALWAYS run packed (round 2 switched at 2048 trajectories: a vector's result then depended on
+    // the size of the batch it travelled in -- the shard a rank owns, the subset a lazy-Jacobian fit re-integrates).  One
+    // trajectory alone in its wavefront costs what it costs in the unpacked kernels; the single-vector methods of the
+    // Python classes ask for SMALL_BATCH and keep the row kernels' lower latency.
+    if (kind == SBM_KIND_SENS && (a.opts.variant == SBM_VARIANT_PACKED || a.opts.variant == SBM_VARIANT_AUTO)) {
       dim3 grid((a.n_traj + 64 / SEG - 1) / (64 / SEG)), block(64);
       if (a.opts.method == SBM_DOPRI45) hipLaunchKernelGGL((sbm_sens_packed_kernel<M, SBM_DOPRI45, SEG>), grid, block, 0, stream, a);
+      else if (a.opts.method == SBM_DOP853) hipLaunchKernelGGL((sbm_sens_packed_kernel<M, SBM_DOP853, SEG>), grid, block, 0, stream, a);
       else hipLaunchKernelGGL((sbm_sens_packed_kernel<M, SBM_RK4_FIXED, SEG>), grid, block, 0, stream, a);
       return (int)hipGetLastError();
     }
@@ -2063,7 +2069,7 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
     if constexpr (kRowGroupOk) {
       if (a.opts.variant == SBM_VARIANT_ROW_GROUP || a.opts.variant == SBM_VARIANT_AUTO ||
           a.opts.variant == SBM_VARIANT_SMALL_BATCH || a.opts.variant == SBM_VARIANT_MFMA ||
-          a.opts.variant == SBM_VARIANT_PACKED || !kPerWaveBuilt || a.opts.method == SBM_DOP853) {
+          a.opts.variant == SBM_VARIANT_PACKED || !kPerWaveBuilt) {
         // Two splits of the same form (emit_rowgroup.py): RG0 for throughput; RG1 -- more, smaller column chunks,
         // fewer elements per lane -- while its wavefronts still find an empty SIMD each (1024 of them): a single
         // parameter vector, a serial optimiser's call, is latency-bound and extra wavefronts are free.
@@ -2099,9 +2105,16 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
       }
     }
     if (a.opts.method == SBM_DOP853) {
-      // beside the row-group form: the row-lane kernel for the smallest models (twelve stage vectors of NV rows per lane)
-      if constexpr (kRowLaneOk && M::NV <= 8) {
-        hipLaunchKernelGGL((sbm_sens_rowlane_kernel<M, SBM_DOP853>), dim3(a.n_traj), dim3(64), 0, stream, a);
+      // beside the row-group form: the row-lane kernel (twelve stage vectors of NV rows per lane: beyond ~16 state
+      // variables they leave the register file and the kernel runs out of scratch -- correct, slow), then the per-wave one
+      if constexpr (kRowLaneOk && M::NV <= 32) {
+        if (a.opts.variant != SBM_VARIANT_PER_WAVE) {
+          hipLaunchKernelGGL((sbm_sens_rowlane_kernel<M, SBM_DOP853>), dim3(a.n_traj), dim3(64), 0, stream, a);
+          return (int)hipGetLastError();
+        }
+      }
+      if constexpr (kPerWaveBuilt && M::NV * ((M::NK + 64) / 64) <= 64) {
+        hipLaunchKernelGGL((sbm_sens_kernel<M, SBM_DOP853>), dim3(a.n_traj), dim3(64), 0, stream, a);
         return (int)hipGetLastError();
       } else {
         return (int)hipErrorInvalidConfiguration;

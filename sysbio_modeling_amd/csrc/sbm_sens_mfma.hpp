@@ -223,9 +223,7 @@ __global__ void __launch_bounds__(64, 1) sbm_sens_mfma_kernel(sbm_kernel_args a)
     }
   };
 
-  SbmTrajOut r;
-  if (METHOD == SBM_DOPRI45) r = sbm_dopri45(sys, z, tg, glen, a.opts, store);
-  else r = sbm_rk4(sys, z, tg, glen, a.opts, store);
+  SbmTrajOut r = sbm_integrate<METHOD>(sys, z, tg, glen, a.opts, store);
 
   if (lane == 0) {
     if constexpr (NCH > 1) {

@@ -680,6 +680,11 @@ class Project(object):
                 oi['max_steps'] = 0          # the budget belongs to the explicit attempt; the kernel's own limit here
                 return split(self._evaluate_once(t, jacobian, want, extrapolate=0, **oi, **keep)) + (None,)
             explicit_method = str(o.get('explicit_method', 'dopri45'))       # 'dop853': the eighth-order pair for the attempt
+            if explicit_method == 'auto':       # the pair by predicted pass time (_lib.predict_explicit_pair)
+                gmod = getattr(self._model, 'generated', None)
+                ch = gmod.rowgroup_chunks() if (gmod is not None and jacobian) else {}
+                explicit_method = _lib.predict_explicit_pair(rtol, V * max(1, len(self._experiments)), ch.get('RG0', 1),
+                                                             ch.get('RG2', 1))[0]
             ex_tol = _lib.implicit_adaptive_defaults(dict(method=explicit_method, rtol=rtol, atol=atol),
                                                      set(integrator_overrides) | set(self.integrator_options))
             out, st, steps, stiff = _control.with_stiff_fallback(

@@ -17,7 +17,7 @@ from .. import _lib
 
 
 def _trial_budget(project, th, integrator_overrides, n_steps_sum=None, status=None):
-    """Step budget of the TRIAL integrations when the caller named none: five times what the slowest TRAJECTORY of the
+    """Step budget of the TRIAL integrations when the caller named none: three times what the slowest TRAJECTORY of the
     starting points needs (at least 2000 attempts), with the early exit (negative ``max_steps``, include/sbm.h).  One
     launch lasts as long as its slowest trajectory, and an optimiser free to wander along unconstrained parameter
     directions finds regions where the model is stiff and a trajectory takes 20 times the usual steps: such a trial point
@@ -48,7 +48,7 @@ def _trial_budget(project, th, integrator_overrides, n_steps_sum=None, status=No
             worst = int(per[ok].max())
     except _lib.SbmError:
         worst = int(n_steps_sum.max()) if n_steps_sum.numel() else 0      # (an upper bound of every trajectory's count)
-    budget = -max(2000, int(5.0 * worst))
+    budget = -max(2000, int(3.0 * worst))
     integrator_overrides['max_steps'] = budget
     return budget
 

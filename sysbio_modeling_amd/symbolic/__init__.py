@@ -150,6 +150,17 @@ class GeneratedModel(object):
                                nnz_jy=len(d.jy), nnz_jp=len(d.jp), nnz_lu=len(pattern))
         return dict(self._flops)
 
+    def rowgroup_chunks(self):
+        """{'RG0': n, 'RG1': n, 'RG2': n}: wavefronts per trajectory of the row-group splits the emitter planned (RG0: DOPRI45 /
+        RK4, RG1: small batches, RG2: DOP853); {} when the model has no row split."""
+        import re
+        out = {}
+        for name in ('RG0', 'RG1', 'RG2'):
+            m = re.search(r'struct %s \{.*?RG_NCH = (\d+)' % name, self.hip_source, re.S)
+            if m:
+                out[name] = int(m.group(1))
+        return out
+
     # -- GPU plugin ---------------------------------------------------------
     def header_path(self):
         from .. import build

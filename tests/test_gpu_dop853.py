@@ -221,3 +221,28 @@ def test_headline_ensemble_256_vectors_against_the_oracle(gpu_models, zoo):
     assert len(over) <= 8
     print("DOP853, 256 vectors: error against LSODA median %.3f p99 %.3f max %.3f parity units; %d beyond 1 (LSODA's own error)"
           % (np.median(err), np.percentile(err, 99), err.max(), len(over)))
+
+
+@pytest.mark.parametrize('model,variant', [('cascade20', 'row_group'), ('cascade20', 'row_lane'), ('cascade20', 'per_wave'),
+                                           ('cascade20', 'mfma'), ('michaelis_menten', 'packed'), ('michaelis_menten', 'row_lane'),
+                                           ('michaelis_menten', 'per_wave'), ('simple', 'packed')])
+def test_dop853_on_every_sensitivity_kernel_variant(gpu_models, golden, zoo, model, variant):
+    """DOP853 answers on every sensitivity kernel (round 2: row-group and the smallest row-lane models only; the other
+    variants returned an error): the real reference's golden vectors through each forced variant, and the same numbers
+    as the method's default kernel to the integration tolerance (the variants take their own step sequences)."""
+    m = gpu_models(model)
+    g = golden({'cascade20': 'cascade20_ref.npz', 'michaelis_menten': 'mm_ref.npz', 'simple': 'simple_ref.npz'}[model])
+    if model == 'cascade20':
+        P, t_out, Yr, Sr = g['P'][:3], _from_zero(g['t'][g['idx']]), g['Y'][:3], g['S'][:3]
+    else:
+        P, t = g['P'], g['t']                       # fixture models on the reference's 1000-point grid (t[0] = 0)
+        idx = np.arange(60, len(t), 90)
+        t_out, Yr, Sr = _from_zero(t[idx]), g['Y'][:, idx], g['S'][:, idx]
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, method='dop853', variant=variant)
+    assert not m.last_info['status'].any()
+    S0, Y0 = m.calc_jacobian_batch(P, t_out, return_states=True, method='dop853')
+    ey, es = parity_err(Y[:, 1:], Yr), parity_err(S[:, 1:], Sr)
+    print("%s dop853 variant %s: vs reference golden y %.3f S %.3f; vs the default kernel y %.3g S %.3g; steps %s"
+          % (model, variant, ey, es, parity_err(Y, Y0), parity_err(S, S0), m.last_info['n_steps']))
+    assert ey <= 1.0 and es <= 1.0
+    assert parity_err(Y, Y0) <= 1.0 and parity_err(S, S0) <= 1.0

@@ -363,3 +363,17 @@ def test_prebuilt_targets_are_used_on_a_box_without_hipcc(tmp_path, monkeypatch)
     monkeypatch.setattr(build, '_hipcc_id', None)
     assert build._locked_build(str(target), cmd_for, [str(src)], 'dummy') == str(target)
     assert build._hipcc_id is None and target.read_bytes() == b'prebuilt'
+
+
+def test_explicit_pair_prediction(zoo):
+    """_lib.predict_explicit_pair (what explicit_method='auto' asks): DOP853 at tight tolerances for every batch size --
+    1.9x with the chip full, ~4x for a single vector, the measured figures of DESIGN.md section 5 -- DOPRI45 from rtol
+    1e-5 up once the chip is full; the row-group splits' wavefront counts come from the generated header."""
+    ch = zoo('cascade20').rowgroup_chunks()
+    assert ch == {'RG0': 1, 'RG1': 5, 'RG2': 2}
+    for n in (1, 256, 2048, 4096, 65536):
+        pair, ratio = _lib.predict_explicit_pair(1e-9, n, ch['RG0'], ch['RG2'])
+        assert pair == 'dop853' and (1.9 < ratio < 2.05 if n > 1024 else 3.8 < ratio < 4.0)
+    assert _lib.predict_explicit_pair(1e-5, 8192, 1, 2)[0] == 'dopri45'
+    assert _lib.predict_explicit_pair(1e-5, 1, 1, 2)[0] == 'dop853'
+    assert zoo('michaelis_menten').rowgroup_chunks().get('RG0') == 1
