@@ -181,70 +181,21 @@ struct SbmImplicitStepper {
   template <int MAXIT>
   __device__ __forceinline__ int newton(double tm, double hh, const double (&y)[RPL], double (&yb)[RPL], double nrtol,
                                         double natol, int& n_iter) {
+    // (since round 3 on the pieces below: a chain Jacobian's update is a parallel prefix over the row lanes, a triangular
+    // one's the fused substitution -- 36 / ~350 instructions where every lane used to repeat the whole substitution and
+    // pick its component out of NV)
     for (int it = 0; it < MAXIT; ++it) {
       ++n_iter;
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) sh->Y[lane + 64 * r] = yb[r];
-      fence();
+      eval_factor(tm, hh, y, yb);
+      double d[RPL];
+      solve_delta(d);
+      float rmax = 0.f;
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
-        double ys[M::RL_MAXYS];
-#pragma unroll
-        for (int q = 0; q < M::RL_MAXYS; ++q) ys[q] = sh->Y[yidx[r][q]];
-        double f = 0.0, jy[M::RL_MAXJY], jp[M::RL_MAXJP];
-#pragma unroll
-        for (int q = 0; q < M::RL_MAXJY; ++q) jy[q] = 0.0;
-#pragma unroll
-        for (int q = 0; q < M::RL_MAXJP; ++q) jp[q] = 0.0;
-        M::class_dispatch(cls[r], tm, ys, ps[r], f, jy, jp);
-        fence();
-#pragma unroll
-        for (int q = 0; q < M::RL_MAXJP; ++q) sh->A[apos[r][q]] = jp[q];
-        if constexpr (!M::IM_TRI && !DIST) {      // (only the redundant form reads the entry list)
-#pragma unroll
-          for (int q = 0; q < M::RL_MAXJY; ++q) sh->JY[jyout[r][q]] = jy[q];
-        }
-        sh->G[lane + 64 * r] = has_row[r] ? (yb[r] - y[r]) - hh * f : 0.0;
-        if constexpr (M::IM_TRI) {
-          double jd = 0.0;
-#pragma unroll
-          for (int q = 0; q < M::RL_MAXJY; ++q) jd = sbm_sel(diagslot[r] == q, jy[q], jd);
-          const double rd = sbm_rcp(fma(-hh, jd, 1.0));
-          sh->MF[rdpos[r]] = rd;
-#pragma unroll
-          for (int q = 0; q < M::RL_MAXJY; ++q) sh->MF[mfpos[r][q]] = hh * jy[q] * rd;
-        } else if constexpr (DIST) {
-          factor_rows(hh, jy);
-        }
+        const double dd = has_row[r] ? d[r] : 0.0;
+        yb[r] -= dd;
+        rmax = fmaxf(rmax, has_row[r] ? sbm_nan_to_inf((float)(fabs(dd) / fma(nrtol, fabs(yb[r]), natol))) : 0.f);
       }
-      fence();
-      double b[NV];
-      if constexpr (DIST) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
-        M::im_solve_lds(sh->MF, sh->RD, b);
-        fence();
-      } else if constexpr (M::IM_TRI) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
-        M::im_solve_tri(sh->MF, b);
-        fence();
-      } else {
-        M::im_build(hh, sh->JY, m);
-        M::im_factor(m);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) b[i] = sh->G[i];
-        fence();
-        M::im_solve(m, b);
-      }
-      float rmax = 0.f;
-      sbm_static_for<RPL>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        constexpr int CNT = (NV - 64 * r) < 64 ? (NV - 64 * r) : 64;
-        const double d = has_row[r] ? sbm_pick_slice<NV, 64 * r, CNT>(b, lane) : 0.0;   // the lane of row i keeps delta_i
-        yb[r] -= d;
-        rmax = fmaxf(rmax, has_row[r] ? sbm_nan_to_inf((float)(fabs(d) / fma(nrtol, fabs(yb[r]), natol))) : 0.f);
-      });
       const float rr = sbm_wave_max(rmax);
       if (!(rr < 3.0e38f)) return SBM_NON_FINITE;
       if (rr <= 1.0f) return SBM_OK;
