@@ -361,6 +361,9 @@ def main():
         # touches a GPU; the N ranks (one per device, backend nccl = RCCL) are children and rank 0 prints the line.
         sys.exit(self_launch(args.gpus))
     protect_stdout()
+    # bench_configs imports this file as module `bench` while it runs as `__main__`: both must see ONE stamp table
+    import bench as _as_module
+    _as_module._CURRENT_STAMPS = _CURRENT_STAMPS
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
