@@ -137,3 +137,28 @@ def test_iex_on_a_stiff_golden_vector_state_only(zoo, golden):
     assert parity_err(Y, g['Y'][0][:4]) <= 1.0 and parity_err(Y, gt['Y'][0][:4]) <= 0.5
     # about three evaluations of f / J_y / J_p per Euler step (quadratically convergent Newton from a cubic predictor)
     assert 2.0 < info['n_eval'] / info['n_euler'] < 3.6
+
+
+def test_wide_stiff_golden_is_the_oracles_call_and_column_groups_give_the_tight_solution(zoo, golden):
+    """stiff50_wide_ref.npz: 32 more vectors of the ensemble through the REAL reference OdeModel
+    (make_golden_stiff_wide.py) -- the oracle's odeint call reproduces their state rows (the 2550-equation sensitivity
+    runs are what the file is for).  And the tight solutions that arbitrate: the augmented system integrated by column
+    groups (odeint_oracle.tight_stiff_solution_by_columns) equals the full-system LSODA run at the same tolerances
+    (stiff50_tight.npz: 15 - 45 minutes per vector) -- checked on half the columns of one vector."""
+    from sysbio_modeling_amd import models_zoo
+    from oracle.tolerances import parity_err
+    gm = zoo('stiff50')
+    w, wt = golden('stiff50_wide_ref.npz'), golden('stiff50_wide_tight.npz')
+    P = models_zoo.stiff_ensemble(4096)[1]
+    assert len(w['P']) == 32 and np.array_equal(w['P'], P[w['index']]) and len(np.unique(w['index'])) == 32
+    assert w['index'].min() >= 3 and w['index'].max() == 4095 and np.array_equal(wt['P'], w['P'])
+    for j in (0, 13, 31):
+        Y = oo.simulate(gm, w['P'][j], w['t'], use_c=True)[w['idx']]
+        assert np.allclose(Y, w['Y'][j], rtol=1e-12, atol=1e-14)
+    # the reference's LSODA results sit about one parity unit from the tight ones, as on the first three vectors
+    worst = max(parity_err(w['S'][j], wt['S'][j]) for j in range(32))
+    assert 0.2 < worst < 3.0 and max(parity_err(w['Y'][j], wt['Y'][j]) for j in range(32)) < 1.0
+    g, gt = golden('stiff50_ref.npz'), golden('stiff50_tight.npz')
+    t = np.concatenate([[0.0], g['t'][g['idx']][:6]])
+    Yc, Sc = oo.tight_stiff_solution_by_columns(gm, g['P'][1], t, group=25)
+    assert parity_err(Yc[1:], gt['Y'][1][:6]) < 1e-2 and parity_err(Sc[1:], gt['S'][1][:6]) < 1e-2
