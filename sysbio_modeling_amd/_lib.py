@@ -179,14 +179,19 @@ def implicit_adaptive_defaults(o, explicit):
         return o
     if str(o.get('method', '')).lower() in IMPLICIT_EXTRAP:
         # Extrapolated implicit Euler: the estimate is the difference of the order-K and order-(K-1) results of a step,
-        # the order-K result is what continues, and the GLOBAL error that accumulates comes out at 1 - 2 x rtol on the
-        # stiff models of the test-suite (stiff50, 35 vectors of the ensemble: worst sensitivity entry 0.5 parity units
-        # = 5e-9 relative at rtol 3e-9 against a tight solution).  Inherited defaults (rtol 1e-9 x size factor, atol
-        # 1e-18: the explicit integrator's) become rtol 3e-9, atol 1e-3 rtol, no step budget.
+        # the order-K result is what continues; the GLOBAL error that accumulates was measured on the 35 stiff50 vectors
+        # the real reference was run on, against their tight solutions (scripts/dev_iex_wide.py, profiles/r03/
+        # iex_wide_tolerances.txt; worst sensitivity entry over the vectors, in parity units of 1e-8 |ref| + 5e-9):
+        #     rtol 3e-9 atol 3e-12: 2.21 (median 0.30)    3e-9 / 3e-13: 0.77    1e-9 / 1e-12: 0.56    1e-9 / 3e-13: 0.32
+        # -- the reference's own LSODA is 1.45 off by the same measure.  Round 3 first took 3e-9 / 3e-12 from the three
+        # vectors of stiff50_ref.npz (0.47 there); the wide pin showed the worst vector at 2.2.  Inherited defaults (rtol
+        # 1e-9 x size factor, atol 1e-18: the explicit integrator's) become rtol 1e-9, atol 3e-4 rtol, no step budget: below
+        # 0.5 units on every vector, so that a result more than one unit from the reference's is always the closer one
+        # to the tight solution.
         if 'rtol' not in explicit:
-            o['rtol'] = max(float(o.get('rtol', 1e-9)), 3e-9)
+            o['rtol'] = max(float(o.get('rtol', 1e-9)), 1e-9)
         if 'atol' not in explicit:
-            o['atol'] = max(float(o.get('atol', 1e-12)), 1e-3 * float(o['rtol']))
+            o['atol'] = max(float(o.get('atol', 1e-12)), 3e-4 * float(o['rtol']))
         if 'max_steps' not in explicit:
             o['max_steps'] = 0
         return o
