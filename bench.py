@@ -322,12 +322,14 @@ _REAL_STDOUT = None
 def protect_stdout():
     """The JSON line must be the only thing on stdout, but ODEPACK (the CPU legs' LSODA) writes its warnings to
     Fortran unit 6 = the C-level stdout, buffered until exit.  So: keep a private duplicate of the real stdout for
-    the JSON line and point file descriptor 1 at stderr for everything else, for the life of the process."""
+    the JSON line and point file descriptor 1 at /dev/null for everything else, for the life of the process."""
     global _REAL_STDOUT
     if _REAL_STDOUT is None:
         sys.stdout.flush()
         _REAL_STDOUT = os.dup(1)
-        os.dup2(2, 1)
+        null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null, 1)         # (not stderr: hundreds of "lsoda-- ..." lines from one CPU leg bury everything else there)
+        os.close(null)
 
 
 def emit(obj):

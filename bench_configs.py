@@ -390,6 +390,9 @@ def run_configs4(model, gm, dev, reps=3, cpu=True):
         fx = run_configs4_fixed(model, gm, dev, reps=reps, cpu=False, setup=(gm5, m5, Pn, P5, t_np, t5, gdir))
         out["fixed_step_pair"] = {k: fx[k] for k in ("ms", "steps", "value", "parity_of_timed_pass", "setting")}
         out["speedup_over_fixed_step_pair"] = fx["ms"] / ms
+        out["fixed_step_pair"]["note"] = ("round 2 chose 4096 + 8192 steps on the three vectors of stiff50_ref.npz; on the 35 "
+                                          "vectors of the wide pin it is NOT at parity (vectors_failed above): the time ratio "
+                                          "compares a controlled integrator with a setting that misses the tolerance")
     except Exception as e:   # noqa: BLE001
         out["fixed_step_pair"] = {"error": repr(e)[:200]}
     if cpu:
@@ -672,6 +675,17 @@ def variant_extras(model, dev, theta_p, tg, rk4_steps):
                                                 note="DOP853 (SBM_DOP853): twelve stages per step, a seventh of the steps; "
                                                      "same parity tests as DOPRI45 (tests/test_gpu_dop853.py)")
     ex["sens_dop853_rtol1e-9_atol1e-12"] = t(_lib.make_opts('dop853', rtol=1e-9, atol=1e-12))
+    # the cost of a Jacobian pass AT PARITY for both explicit pairs, side by side (round 2's tightening of the default atol
+    # doubled DOPRI45's steps per pass; DOP853 gives it back), and what explicit_method='auto' would pick for this batch
+    pick = _lib.predict_explicit_pair(tol['rtol'], int(V), 1, 2)
+    ex["ms_per_pass_at_parity"] = {
+        "dopri45": ex["sens_dopri45_default_tolerances"].get("ms"), "dop853": ex["sens_dop853_default_tolerances"].get("ms"),
+        "dopri45_round1_tolerances_rtol1e-9_atol1e-12": ex.get("sens_dopri45_auto", {}).get("ms"),
+        "explicit_method_auto_picks": pick[0], "predicted_time_ratio_dopri45_over_dop853": pick[1],
+        "measured_time_ratio": (ex["sens_dopri45_default_tolerances"].get("ms") or 0.0) / max(ex["sens_dop853_default_tolerances"].get("ms") or 1.0, 1e-9),
+        "note": "kernel alone, 4096 vectors x 820 ODEs, OdeModel's default tolerances (DOP853 at a tenth of the inherited rtol, as "
+                "the Python classes run it); both meet SURVEY 8(d) against tight solutions (tests/test_gpu_parity_sweeps.py, "
+                "tests/test_gpu_dop853.py)"}
     # the reference's own fixture size: Michaelis-Menten (2 states, 5 parameters: 12 coupled ODEs), 4096 vectors with
     # sensitivities -- one trajectory per wavefront (row-group / row-lane) against eight per wavefront (packed)
     try:
