@@ -10,6 +10,8 @@ bench.py quotes it.
 """
 import json
 import os
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")      # one core, honestly: LAPACK would otherwise use them all
+os.environ.setdefault("OMP_NUM_THREADS", "1")
 import platform
 import sys
 import time
