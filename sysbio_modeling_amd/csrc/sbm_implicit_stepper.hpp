@@ -365,8 +365,20 @@ struct SbmImplicitStepper {
   // one midpoint step of a sensitivity column with the matrices newton() left: z <- 2 M^-1 (z + hh J_p) - z
   __device__ __forceinline__ void sens(double hh, double (&z)[NV]) {
     double b[NV];
+    if constexpr (Sh::A_SPARSE) {
+      int lo = lane + 64 * chunk;  // (opaque: see solve_delta)
+      asm volatile("" : "+v"(lo));
 #pragma unroll
-    for (int i = 0; i < NV; ++i) b[i] = fma(hh, a_of(i), z[i]);
+      for (int i = 0; i < NV; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < M::RL_MAXJP; ++q) a = sbm_sel(M::rl_jpcol(q, i) == lo, sh->A[i * M::RL_MAXJP + q], a);
+        b[i] = fma(hh, a, z[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) b[i] = fma(hh, a_of(i), z[i]);
+    }
     if constexpr (DIST) M::im_solve_lds(sh->MF, sh->RD, b);
     else if constexpr (M::IM_TRI) M::im_solve_tri(sh->MF, b);
     else M::im_solve(m, b);

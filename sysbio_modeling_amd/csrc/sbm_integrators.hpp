@@ -1799,9 +1799,12 @@ __device__ __forceinline__ double sbm_pick_tree(const double (&v)[N], int lane) 
 
 template <class M>
 struct SbmImidShared {
-  static constexpr bool A_SPARSE = false;
+  // J_p reaches the columns through a compact per-row table (RL_MAXJP values, picked by column index) when rows have few
+  // parameter entries -- round 2 kept the dense [row][64] image here (25.6 KB for 50 rows: five wavefronts per CU); with
+  // the compact table and the fused Newton update (256 VGPRs) two wavefronts share a SIMD
+  static constexpr bool A_SPARSE = (M::RL_MAXJP <= 4);
   static constexpr int NROW = 64 * ((M::NV + 63) / 64);
-  static constexpr int A_SIZE = M::NV * 64 + 2;
+  static constexpr int A_SIZE = A_SPARSE ? (M::NV * M::RL_MAXJP + 2) : (M::NV * 64 + 2);
   double Y[NROW];               // iterate, one component per row lane (rows lane, lane + 64, ...)
   double G[NROW];               // Newton residual
   double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
