@@ -470,27 +470,33 @@ def _silence_fortran_unit6():
 
 
 def stiff_cpu_legs(gm5, Pn, t_np):
-    """CPU legs of configs[4] on one host core, vector #3 of the ensemble:
-      as_reference   the reference's default call -- odeint, Dfun=None: LSODA differences a dense 2550 x 2550 Jacobian --
-                     over t in [0, 1], a tenth of the span (the whole span takes 45 - 150 s per vector);
+    """CPU legs of configs[4] on ONE host core (BLAS limited to one thread), vector #3 of the ensemble:
+      as_reference   the reference's default call -- odeint, Dfun=None: LSODA differences and factors a dense 2550 x 2550
+                     Jacobian -- over the FULL span on the reference's 1000-point grid (~35 s);
       analytic_dfun  the reference's use_jac path (model/ode_model.py:114-120) with the generated analytic Jacobian of the
-                     augmented system as Dfun, over t in [0, 0.1]; the full-span timings of both calls are measured once per
-                     round (scripts/cpu_leg_stiff50.py -> profiles/r03/stiff50_cpu_full_span.json) and quoted from there."""
+                     augmented system as Dfun, over t in [0, 0.1]; its full-span timing is measured once per round
+                     (scripts/cpu_leg_stiff50.py -> profiles/r03/stiff50_cpu_full_span.json) and quoted from there."""
     from oracle import odeint_oracle as oo
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        import contextlib
+        threadpool_limits = lambda limits=None: contextlib.nullcontext()     # noqa: E731
     gm5.c_library()
     p = Pn[3]
     grid = np.linspace(0.0, 10.0, 1000)
     restore = _silence_fortran_unit6()
     try:
+      with threadpool_limits(limits=1):
         t0 = time.perf_counter()
-        (_, _), info = oo.calc_jacobian(gm5, p, grid[:101], use_c=True, return_states=True, full_output=True)
+        (_, _), info = oo.calc_jacobian(gm5, p, grid, use_c=True, return_states=True, full_output=True)
         dt = time.perf_counter() - t0
         legs = {"value": int(info['nst'][-1]) / dt, "unit": "ODE-steps/s", "cores": 1, "kind": "port",
-                "sample": "1 vector (#3 of the ensemble) over t in [0, 1] (the first 100 of the 1000 grid points): "
+                "sample": "1 vector (#3 of the ensemble) over the FULL span t in [0, 10] on the reference's 1000-point grid: "
                           "scipy.integrate.odeint rtol=atol=1e-10, 2550 ODEs, compiled C RHS, Dfun=None as in the reference's "
-                          "default call; %.1f s, %d LSODA steps, %d Jacobian evaluations"
+                          "default call, BLAS on one thread; %.1f s, %d LSODA steps, %d Jacobian evaluations"
                           % (dt, int(info['nst'][-1]), int(info['nje'][-1])),
-                "seconds": dt, "span_covered": [0.0, float(grid[100])]}
+                "seconds": dt, "seconds_per_vector": dt, "span_covered": [0.0, 10.0]}
         # the use_jac path on a shorter span (the Python callback fills a 2550 x 2550 matrix per Jacobian evaluation)
         jac = gm5.sens_model_jac
         n_pts = 11
