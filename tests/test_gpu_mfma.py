@@ -100,15 +100,22 @@ def test_packed_sensitivity_kernel_on_the_reference_fixtures(gpu_models, golden,
     assert m.last_info['status'][ok].tolist() == [0] * 8 and np.array_equal(Sd[ok], Sb[ok])
 
 
-def test_packed_kernel_is_what_large_batches_of_small_models_run(gpu_models, golden):
-    """AUTO from 2048 trajectories on: same numbers as the forced variant."""
+def test_a_batch_rows_do_not_depend_on_the_size_of_the_batch(gpu_models, golden):
+    """AUTO runs small models on the packed kernel for EVERY batch size (round 2 switched kernels at 2048 trajectories:
+    a vector's numbers then depended on the batch it travelled in -- the shard a rank owns, the subset a lazy-Jacobian
+    fit re-integrates): 4096 vectors in one call, as two shards of 2048, and in odd subsets below the old threshold, bit
+    for bit; both explicit pairs."""
     m = gpu_models('michaelis_menten')
     g = golden('mm_ref.npz')
     rng = np.random.default_rng(6)
-    P = g['P'][:1] * np.exp(0.2 * rng.standard_normal((2048, 5)))
+    P = g['P'][:1] * np.exp(0.2 * rng.standard_normal((4096, 5)))
     t = np.linspace(0, 100, 6)
-    Sa = m.calc_jacobian_batch(P, t)
-    Sb = m.calc_jacobian_batch(P, t, variant='packed')
-    assert np.array_equal(Sa, Sb)
-    Sc = m.calc_jacobian_batch(P[:64], t, variant='packed')
-    assert np.array_equal(Sc, Sb[:64])
+    for method in ('dopri45', 'dop853'):
+        Sa, Ya = m.calc_jacobian_batch(P, t, return_states=True, method=method)
+        assert not m.last_info['status'].any()
+        assert np.array_equal(m.calc_jacobian_batch(P, t, variant='packed', method=method), Sa)
+        for lo, hi in ((0, 2048), (2048, 4096), (100, 137), (4000, 4001), (0, 2047)):
+            Sb, Yb = m.calc_jacobian_batch(P[lo:hi], t, return_states=True, method=method)
+            assert np.array_equal(Sb, Sa[lo:hi]) and np.array_equal(Yb, Ya[lo:hi]), (method, lo, hi)
+        pick = np.array([5, 3000, 77, 2049])
+        assert np.array_equal(m.calc_jacobian_batch(P[pick], t, method=method), Sa[pick])
