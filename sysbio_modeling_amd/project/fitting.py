@@ -18,7 +18,8 @@ from .. import _lib
 
 def _trial_budget(project, th, integrator_overrides, n_steps_sum=None, status=None):
     """Step budget of the TRIAL integrations when the caller named none: three times what the slowest TRAJECTORY of the
-    starting points needs (at least 2000 attempts), with the early exit (negative ``max_steps``, include/sbm.h).  One
+    starting points needs (at least 300 attempts: DOP853 takes ~170 steps where DOPRI45 takes ~1000, and a floor of 2000 let its
+    stiff trial points run twelve times the typical trajectory), with the early exit (negative ``max_steps``, include/sbm.h).  One
     launch lasts as long as its slowest trajectory, and an optimiser free to wander along unconstrained parameter
     directions finds regions where the model is stiff and a trajectory takes 20 times the usual steps: such a trial point
     is worth rejecting by its price alone -- the trust region then shrinks away from it.  (Measured on the sloppy
@@ -48,7 +49,12 @@ def _trial_budget(project, th, integrator_overrides, n_steps_sum=None, status=No
             worst = int(per[ok].max())
     except _lib.SbmError:
         worst = int(n_steps_sum.max()) if n_steps_sum.numel() else 0      # (an upper bound of every trajectory's count)
-    budget = -max(2000, int(3.0 * worst))
+    # the same cost-quality trade-off for both pairs (scripts/dev_fit_budget.py, 256 starts x 100 iterations of the configs[3]
+    # project: median cost 184.6 - 184.8 at 1.2 s with 3x for DOPRI45 (~3 900 attempts) and 6x for DOP853 (~1 200); half the
+    # budget: 184.75 / 185.0 at 1.2 / 1.0 s, 185.6 at 0.8 s with 3x for DOP853; twice: 184.3 / 184.5 at 1.9 / 1.4 s)
+    method = str(project._options(**integrator_overrides).get('method', 'dopri45')).lower()
+    factor = 6.0 if method in _lib.DOP853 else 3.0
+    budget = -max(300, int(factor * worst))
     integrator_overrides['max_steps'] = budget
     return budget
 

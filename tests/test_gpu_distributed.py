@@ -127,3 +127,28 @@ def test_two_rccl_ranks_one_per_device(tmp_path):
     assert np.array_equal(a, b) and a.shape == (37,)
     proj, thetas = _build_project()
     assert np.array_equal(a, proj.evaluate_batch(thetas)['norms'])
+
+
+def test_bench_multi_rank_line_on_one_gpu():
+    """`python bench.py --gpus 2` end to end in rehearsal mode (SBM_BENCH_REHEARSAL=1: both ranks on GPU 0, gloo instead of
+    RCCL -- RCCL refuses two ranks on one device): the launcher spawns its ranks itself, rank 0 prints ONE JSON line with
+    the weak-scaling headline AND the configuration BASELINE.json names for the multi-GPU run, configs[3], sharded by
+    vector over the ranks (strong scaling), every rank finding its own block in the gathered norms."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SBM_BENCH_REHEARSAL='1')
+    p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 1e8 and d['config']['failed_vectors'] == 0
+    assert d['ranks']['world_size_seen'] == 2 and d['ranks']['gathered_norms_match_local_block']
+    c3 = d['configs']['configs3_sharded']
+    assert 'error' not in c3, c3
+    assert c3['n_gpus'] == 2 and c3['vectors_per_rank'] == [512, 512] and c3['scaling'] == 'strong'
+    assert c3['failed_vectors'] == 0 and c3['gathered_norms_match_local_block_on_every_rank'] and c3['value'] > 1e8
