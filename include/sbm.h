@@ -128,7 +128,7 @@ typedef struct sbm_integrator_opts {
 enum { SBM_VARIANT_AUTO = 0, SBM_VARIANT_PER_WAVE = 1, SBM_VARIANT_ROW_LANE = 2, SBM_VARIANT_ROW_GROUP = 3,
        /* AUTO, except that the ROW_GROUP kernel takes its small-batch split -- more, smaller column chunks, fewer
         * equations per lane: the work of ONE wavefront per step is what a call with a single parameter vector
-        * waits for -- while n_traj x chunks <= 1024 (a SIMD each).  The two splits take different step sequences:
+        * waits for -- while n_traj x chunks <= 2048 (two resident wavefronts per SIMD).  The two splits take different step sequences:
         * results agree to the integration tolerance, not bit for bit, which is why AUTO never switches by itself
         * (a batch call's rows do not depend on the size of the batch). */
        SBM_VARIANT_SMALL_BATCH = 4,

@@ -2010,10 +2010,11 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
   }
   // J_y S on the matrix cores (sbm_sens_mfma.hpp) costs the same whatever the sparsity of J_y; the scalar kernels cost
   // 2 FMAs per non-zero and column.  Measured on 20-state networks, 4096 vectors, DOPRI45 (bench.py "dense",
-  // profiles/r02): 40 non-zeros (cascade20) 5.2 ms scalar / 27 ms MFMA at twice the steps; 120: 8.9 / 14.9; 220: 26.7 /
-  // 16.8; 400 (dense): 65.0 / 21.7 -- the matrix cores win from about 45 % density.  AUTO takes them from there
-  // (a static property of the model: a given model always runs the same kernel); SBM_VARIANT_MFMA forces them.
-  constexpr bool kMfmaPays = M::NV >= 16 && M::NV <= 64 && (long long)M::NNZ_JY * 100 >= 45LL * M::NV * M::NV;
+  // profiles/r03, scalar / MFMA ms): 40 non-zeros (cascade20, twice the steps) 5.3 / 21.7; 60: 4.0 / 11.1; 120: 9.3 / 11.5;
+  // 220: 25.7 / 12.1; 400 (dense): 67.1 / 13.4 -- the matrix cores win from about 35 % density (round 2, one wavefront per
+  // SIMD: 45 %).  AUTO takes them from there (a static property of the model: a given model always runs the same
+  // kernel); SBM_VARIANT_MFMA forces them.
+  constexpr bool kMfmaPays = M::NV >= 16 && M::NV <= 64 && (long long)M::NNZ_JY * 100 >= 35LL * M::NV * M::NV;
   // (DOP853 keeps twelve stage vectors alive -- on the matrix-core kernel they leave the register file: built, so that a
   // forced variant answers, but AUTO keeps DOP853 on the row kernels)
   if (kind == SBM_KIND_SENS && (a.opts.variant == SBM_VARIANT_MFMA ||
@@ -2074,12 +2075,13 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
           a.opts.variant == SBM_VARIANT_SMALL_BATCH || a.opts.variant == SBM_VARIANT_MFMA ||
           a.opts.variant == SBM_VARIANT_PACKED || !kPerWaveBuilt) {
         // Two splits of the same form (emit_rowgroup.py): RG0 for throughput; RG1 -- more, smaller column chunks,
-        // fewer elements per lane -- while its wavefronts still find an empty SIMD each (1024 of them): a single
-        // parameter vector, a serial optimiser's call, is latency-bound and extra wavefronts are free.
+        // fewer elements per lane -- while all its wavefronts are resident at once (2048: two per SIMD; a wavefront of
+        // this split issues ~40 % of the other's instructions per step, so two of them sharing a SIMD still finish a step
+        // sooner than one of the other alone): a single parameter vector, a serial optimiser's call, is latency-bound.
         // Opt-in (SBM_VARIANT_SMALL_BATCH: what the single-vector methods of the Python classes ask for): the two
         // splits take different step sequences, and a batch call's rows must not depend on how many rows it has.
         const bool small_batch = !std::is_same<typename M::RG1, typename M::RG0>::value &&
-                                 a.opts.variant == SBM_VARIANT_SMALL_BATCH && (long long)a.n_traj * M::RG1::RG_NCH <= 1024;
+                                 a.opts.variant == SBM_VARIANT_SMALL_BATCH && (long long)a.n_traj * M::RG1::RG_NCH <= 2048;
         auto go = [&](auto layout_tag) -> int {
           using L = typename decltype(layout_tag)::type;
           dim3 grid(a.n_traj, L::RG_NCH), block(64);

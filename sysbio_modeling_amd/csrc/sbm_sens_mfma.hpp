@@ -142,13 +142,24 @@ template <class M>
 struct SbmMfmaPlan {
   static constexpr int RT = (M::NV + 15) / 16;
   static constexpr int CT_ALL = (M::NK + 15) / 16;
-  static constexpr int CT_FIT = (24 / (4 * RT)) > 0 ? (24 / (4 * RT)) : 1;
+// Elements of S per lane.  Round 2 planned up to 24 (cascade20: one wavefront per trajectory, 24 elements x 7 stage vectors:
+// all 512 registers, 460 B of scratch, one wavefront per SIMD, VALU active 32 %); with at most 12 (16 columns per
+// wavefront, three wavefronts per trajectory, each repeating the state evaluation) the kernel needs 254 registers, no
+// scratch, and TWO wavefronts share a SIMD -- the matrix pipe of one runs under the Runge-Kutta combinations of the other.
+// Measured (4096 vectors, DOPRI45, ms per launch, 24 -> 12): dense20 23.6 -> 13.4, half density 17.2 -> 12.1, quarter 14.9 ->
+// 11.5, cascade20 27.1 -> 21.7 (profiles/r03/dense_*).
+#ifndef SBM_MFMA_MAX_EL
+#define SBM_MFMA_MAX_EL 12
+#endif
+  static constexpr int CT_FIT = (SBM_MFMA_MAX_EL / (4 * RT)) > 0 ? (SBM_MFMA_MAX_EL / (4 * RT)) : 1;
   static constexpr int CT = CT_ALL < CT_FIT ? CT_ALL : CT_FIT;
   static constexpr int NCH = (M::NK + 16 * CT - 1) / (16 * CT);
+  // seven stage vectors of 4 RT CT elements + the A operands: up to 12 elements per lane fit 256 registers
+  static constexpr int MIN_WAVES = (4 * RT * CT <= 12) ? 2 : 1;
 };
 
 template <class M, int METHOD>
-__global__ void __launch_bounds__(64, 1) sbm_sens_mfma_kernel(sbm_kernel_args a) {
+__global__ void __launch_bounds__(64, SbmMfmaPlan<M>::MIN_WAVES) sbm_sens_mfma_kernel(sbm_kernel_args a) {
   constexpr int CT = SbmMfmaPlan<M>::CT, NCH = SbmMfmaPlan<M>::NCH;
   using Sys = MfmaSystem<M, CT>;
   using Sh = SbmMfmaShared<M, CT>;

@@ -93,7 +93,7 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     experiments 0.86 s eager / 0.97 s lazy per 100 iterations; see DESIGN.md section 6 for larger batches).
 
     With a handful of starts the chip is mostly empty: ``variant='small_batch'`` (an integrator override) lets the
-    sensitivity kernel use its small-batch split while starts x experiments x chunks <= 1024.
+    sensitivity kernel use its small-batch split while starts x experiments x chunks <= 2048.
 
     Returns a dict of numpy arrays: theta (V, q), cost (V,) = 0.5 |r|^2, n_iter (V,) iterations until
     convergence (max_iter if never), converged (V,) bool, n_evaluations (total trial points integrated),
