@@ -25,7 +25,10 @@ def test_mfma_variant_equals_the_scalar_kernels_on_cascade20(gpu_models, golden,
     na = m.last_info['n_steps'].copy()
     Sb, Yb = m.calc_jacobian_batch(P, t_out, return_states=True, method=method, variant='mfma', **kw)
     assert m.last_info['status'].tolist() == [0] * 7
-    assert np.all(np.abs(m.last_info['n_steps'] - na) <= 2)              # same controller, same step sequence
+    # the same controller -- per column chunk: since round 3 the matrix-core kernel runs 16 columns per wavefront (three
+    # wavefronts per trajectory here), each under the error norm of ITS columns: a few per cent fewer steps than the
+    # one-wavefront kernel, whose norm is the maximum over all columns (the count reported is the largest chunk's)
+    assert np.all(m.last_info['n_steps'] <= na + 2) and np.all(m.last_info['n_steps'] >= 0.9 * na)
     assert np.allclose(Ya, Yb, rtol=1e-9, atol=1e-11) and np.allclose(Sa, Sb, rtol=1e-9, atol=1e-10)
     if method == 'dopri45':
         assert parity_err(Yb[:4, 1:], g['Y']) <= 1.0 and parity_err(Sb[:4, 1:], g['S']) <= 1.0
