@@ -639,3 +639,56 @@ def test_dense_coupled_stiff_network_row_distributed_lu():
                      what='dense20 stiff vector %d' % v, criterion='parity')
     print("dense20 stiff: implicit_controlled %s coarse steps; DOPRI45 with a 20000-step budget: status %s"
           % (m.last_info['n_steps'], explicit_status))
+
+
+def test_stiff_integrator_edge_cases(gpu_models, zoo):
+    """SBM_IMPLICIT_EXTRAP at the edges of its input space: a single output at the initial time; a start time other than
+    zero with non-zero initial state AND sensitivities (odeint semantics, model/ode_model.py:122,167); a parameter vector
+    that cannot be integrated next to ones that can (NaN rows and a non-zero status for it alone); a step budget that
+    runs out; every extrapolation order the entry point admits."""
+    from oracle import odeint_oracle as oo
+    m, gm = gpu_models('michaelis_menten'), zoo('michaelis_menten')
+    p = rc.MM_PARAMS * np.array([40.0, 30.0, 5.0, 3.0, 20.0])
+    P = np.stack([p, 0.5 * p, 2.0 * p])
+    kw = dict(method='implicit_extrap')
+    # one output row, at t0: the initial condition, zero steps
+    S, Y = m.calc_jacobian_batch(P, np.array([0.0]), return_states=True, **kw)
+    assert m.last_info['status'].tolist() == [0, 0, 0] and m.last_info['n_steps'].tolist() == [0, 0, 0]
+    assert np.all(Y == 0.0) and np.all(S == 0.0) and S.shape == (3, 1, 10)
+    # t_sim[0] = 7.5 is the time of the initial condition; y0 and S0 given
+    rng = np.random.default_rng(2)
+    y0 = np.concatenate([[0.4, 0.9], 0.1 * rng.standard_normal(10)])
+    t2 = np.linspace(7.5, 60.0, 300)
+    pick = [0, 40, 299]
+    Sr, Yr = oo.calc_jacobian(gm, P[1], t2, init_conditions=y0, return_states=True)
+    S2, Y2 = m.calc_jacobian_batch(P[1:2], t2[pick], init_conditions=y0, return_states=True, **kw)
+    assert np.array_equal(Y2[0, 0], y0[:2]) and np.array_equal(S2[0, 0], y0[2:])
+    assert parity_err(Y2[0], Yr[pick]) <= 1.0 and parity_err(S2[0], Sr[pick]) <= 1.0
+    # a vector that cannot be integrated does not take its neighbours with it
+    Pbad = P.copy()
+    Pbad[1, 0] = np.nan
+    t3 = np.array([0.0, 10.0, 50.0])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        S3, Y3 = m.calc_jacobian_batch(Pbad, t3, return_states=True, **kw)
+        st = m.last_info['status'].copy()
+        Sg, Yg = m.calc_jacobian_batch(P, t3, return_states=True, **kw)
+    assert st[0] == 0 and st[2] == 0 and st[1] != 0
+    assert np.all(np.isnan(Y3[1, 1:])) and np.all(np.isnan(S3[1, 1:]))
+    assert np.array_equal(Y3[[0, 2]], Yg[[0, 2]]) and np.array_equal(S3[[0, 2]], Sg[[0, 2]])
+    # the step budget counts macro steps
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m.calc_jacobian_batch(P[:1], t3, max_steps=3, **kw)
+    assert m.last_info['status'].tolist() == [1]
+    # every order: higher orders take fewer macro steps at a tight tolerance; all agree with the reference
+    tt = np.linspace(0, 50.0, 1000)
+    Srr, Yrr = oo.calc_jacobian(gm, P[0], tt, return_states=True)
+    steps = []
+    for K in (2, 3, 4, 6, 8, 10):
+        So, Yo = m.calc_jacobian_batch(P[:1], tt[[0, 400, 999]], return_states=True, rtol=1e-8 if K > 3 else 1e-6, atol=1e-12, order=K, **kw)
+        assert m.last_info['status'].tolist() == [0]
+        steps.append(int(m.last_info['n_steps'][0]))
+        tol = 1.0 if K > 3 else 300.0
+        assert parity_err(Yo[0], Yrr[[0, 400, 999]]) <= tol and parity_err(So[0], Srr[[0, 400, 999]]) <= tol, K
+    assert steps[3] > steps[4] and steps[2] > steps[3], steps
