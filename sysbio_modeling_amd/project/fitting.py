@@ -474,8 +474,21 @@ def _trust_region_fused(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         _lib.check(lib.sbm_lm_trust_step_ex(ctx.handle, p(cur['J']), p(cur['r']), p(dscale), p(radius), p(lam), V, M, q,
                                             p(row_scale), p(done), float(max_step), p(th), p(trial), p(delta), p(pred),
                                             p(dxnorm), p(gtx), p(st)), 'sbm_lm_trust_step_ex')
+        if trace:
+            import time
+            torch.cuda.synchronize(dev)
+            t_launch = time.perf_counter()
         integrate(trial, opts_t, tr, not lazy_jacobian)
         n_eval += V
+        if trace:
+            # what the trial launch cost and why: it lasts as long as its slowest trajectory (scripts/dev_fit_trace.py)
+            torch.cuda.synchronize(dev)
+            t_launch = time.perf_counter() - t_launch
+            per = torch.empty((V, max(1, len(project._experiments))), dtype=i32, device=dev)
+            _lib.check(lib.sbm_project_trajectory_steps(proj, V, p(per)), 'sbm_project_trajectory_steps')
+            launch = dict(ms=1e3 * t_launch, steps_max=int(per.max()), steps_mean=float(per.double().mean()),
+                          steps_p99=float(per.double().flatten().quantile(0.99)), failed=int((tr['status'] != 0).sum()),
+                          done=int((done != 0).sum()))
         cost_prev = cost.clone() if trace else None
         _lib.check(lib.sbm_lm_update(ctx.handle, p(cost), p(tr['norms']), p(tr['status']), p(pred), p(dxnorm), p(gtx), p(st),
                                      p(th), p(dscale), V, q, float(ftol), float(xtol), it, 1 if it == 0 else 0, p(radius),
@@ -504,7 +517,7 @@ def _trust_region_fused(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         if trace:
             running = done == 0
             md = lambda t: float(t[running].median()) if bool(running.any()) else 0.0     # noqa: E731
-            history.append(dict(iteration=it, accepted=n_acc, live=live, cost_median=float(cost.median()),
+            history.append(dict(iteration=it, accepted=n_acc, live=live, launch=launch, cost_median=float(cost.median()),
                                 lambda_median=md(lam), radius_median=md(radius), ratio_median=md(ratio),
                                 rel_decrease_median=md((cost_prev - cost) / cost_prev)))
         if live == 0:
