@@ -70,7 +70,7 @@ struct SbmIexShared {
   static constexpr int MF_SIZE = sbm_imf_size<M>(), RD_SIZE = sbm_ird_size<M>();
   __attribute__((aligned(16))) double MF[MF_SIZE];   // the factors (sbm_implicit_stepper.hpp)
   double RD[RD_SIZE];
-  double A[A_SIZE];             // J_p: [row][slot] or [row][column]
+  __attribute__((aligned(16))) double A[A_SIZE];   // J_p: [row][slot] or [row][column]; aligned: im_sens_tri reads pairs
   static constexpr int ZC = M::NK < 64 ? M::NK : 64;     // columns of a chunk that exist
   static constexpr int ZS = ZC < 64 ? ZC + 1 : 64;       // + one spare column that the idle lanes share (all zeros)
   double ZN[M::NV * ZS];        // S at the start of the macro step, [row][column]

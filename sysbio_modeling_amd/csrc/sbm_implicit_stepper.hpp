@@ -390,7 +390,14 @@ struct SbmImplicitStepper {
   // one implicit-EULER step (hh = the step) of a sensitivity column with the matrices newton() left, in place:
   // z <- M^-1 (z + hh J_p) -- the exact derivative of y_{n+1} = y_n + hh f(y_{n+1})  (sbm_implicit_extrap.hpp)
   __device__ __forceinline__ void sens_euler(double hh, double (&z)[NV]) {
-    if constexpr (Sh::A_SPARSE) {
+    if constexpr (Sh::A_SPARSE && M::IM_SENS_TRI && !DIST) {
+      // triangular M: pick and substitution row by row, tables loaded a block ahead (emit_implicit.py)
+      int lo = lane + 64 * chunk;  // (opaque: see solve_delta)
+      asm volatile("" : "+v"(lo));
+      M::im_sens_tri(sh->MF, sh->A, hh, lo, z);
+      fence();
+      return;
+    } else if constexpr (Sh::A_SPARSE) {
       int lo = lane + 64 * chunk;  // (opaque: see solve_delta)
       asm volatile("" : "+v"(lo));
 #pragma unroll

@@ -217,6 +217,59 @@ def emit_members(spec, d):
             if i % 8 == 7 and i + 1 < n:
                 L.append("    SBM_LDS_FENCE();")
         L += ["  }"]
+        # The sensitivity step of the extrapolation kernel, fused: z <- M^-1 (z + hh J_p[:, column of this lane]).  Row by
+        # row the J_p pick (independent of the chain) sits next to the substitution (dependent on the previous row), and
+        # the table entries of the NEXT block of rows are loaded before the arithmetic of the current one: written as two
+        # passes (all picks, then im_solve_tri with its fences) the substitution had three ds_read_b128 in flight and
+        # every block of eight rows began by waiting out a full LDS round trip (ISA of stiff50, round 3).
+        blocks, cur, width = [], [], 0
+        for i in range(n):
+            w = 1 + sum(1 for (r, c) in pattern if r == i and c < i)
+            w += w & 1
+            if cur and width + w > 8:
+                blocks.append(cur)
+                cur, width = [], 0
+            cur.append(i)
+            width += w
+        blocks.append(cur)
+        row_end = lambda i: (rstart[i + 1] if i + 1 < n else n_table)     # noqa: E731
+
+        def loads(b):
+            rows_b = blocks[b]
+            lo_e, hi_e = rstart[rows_b[0]], row_end(rows_b[-1])
+            return ["    double t%d[%d], a%d[%d * IM_JP];  // rows %d..%d" % (b, hi_e - lo_e, b, len(rows_b), rows_b[0], rows_b[-1]),
+                    "    _Pragma(\"unroll\") for (int e = 0; e < %d; ++e) t%d[e] = mf[%d + e];" % (hi_e - lo_e, b, lo_e),
+                    "    _Pragma(\"unroll\") for (int e = 0; e < %d * RL_MAXJP; ++e) a%d[e] = ja[%d * RL_MAXJP + e];"
+                    % (len(rows_b), b, rows_b[0])]
+
+        def pick(b, i):
+            # (tried: the pick as ONE v_fmac under a one-lane EXEC set from literals by scalar instructions, 3 instead of
+            # 6 vector instructions per row -- 105 ms against 106 for configs[4]: the vector pipe is not what this kernel
+            # waits for at one wavefront per SIMD; not kept)
+            rows_b = blocks[b]
+            expr = "0.0"
+            for q, (_, c) in reversed(list(enumerate(d.jp_rows[i]))):
+                expr = "SBM_SEL(col == %d, a%d[%d * RL_MAXJP + %d], %s)" % (c, b, i - rows_b[0], q, expr)
+            return ["    z[%d] = fma(hh, %s, z[%d]);" % (i, expr, i)] if d.jp_rows[i] else []
+        L += ["  // z <- M^-1 (z + hh * J_p[:, column of this lane]) with the J_p table `ja` ([row][RL_MAXJP], columns rl_jpcol), the",
+              "  // factors `mf`; col = the sensitivity column of this lane",
+              "  static constexpr bool IM_SENS_TRI = true;",
+              "  static constexpr int IM_JP = RL_MAXJP > 0 ? RL_MAXJP : 1;",
+              "  __device__ __forceinline__ static void im_sens_tri(const double* mf, const double* ja, double hh, int col, double (&z)[NV]) {\n    (void)col;"]
+        L += loads(0)
+        for b, rows_b in enumerate(blocks):
+            L.append("    SBM_LDS_FENCE();")
+            if b + 1 < len(blocks):
+                L += loads(b + 1)
+            base = rstart[rows_b[0]]
+            for i in rows_b:
+                L += pick(b, i)
+                expr = "t%d[%d] * z[%d]" % (b, rstart[i] - base, i)
+                for (r, c) in pattern:
+                    if r == i and c < i:
+                        expr = "fma(t%d[%d], z[%d], %s)" % (b, pos[(r, c)] - base, c, expr)
+                L.append("    z[%d] = %s;" % (i, expr))
+        L += ["  }"]
         L += ["  static constexpr int IM_MF = %d;     // entries of the table (rows padded to even starts)" % n_table]
         # a CHAIN (row i refers to row i - 1 only: a cascade): the Newton update of the state is a first-order linear
         # recurrence x_i = b_i + a_i x_{i-1} over the row lanes -- a parallel prefix (sbm_implicit_stepper.hpp)
@@ -227,6 +280,8 @@ def emit_members(spec, d):
     L += ["  __device__ __forceinline__ static void im_solve_tri(const double*, double (&)[NV]) {}",
           "  template <int RPL>",
           "  __device__ __forceinline__ static void im_solve_tri_pick(const double*, const double*, int, double (&)[RPL]) {}",
+          "  static constexpr bool IM_SENS_TRI = false;",
+          "  __device__ __forceinline__ static void im_sens_tri(const double*, const double*, double, int, double (&)[NV]) {}",
           "  static constexpr int IM_MF = IM_NM;",
           "  static constexpr bool IM_CHAIN = false;"]
     L += emit_distributed(spec, d, pattern, ops)
