@@ -265,7 +265,19 @@ struct SbmImplicitStepper {
   // one level of the prefix: (a, b)_i <- (a, b)_i o (a, b)_src, i.e. x_i = b_i + a_i x_src expressed through x_(src's source)
   template <int CTRL, int ROW_MASK>
   __device__ __forceinline__ static void chain_level(double& a, double& b) {
-    const double ap = dpp_f64<CTRL, ROW_MASK>(a, 1.0), bp = dpp_f64<CTRL, ROW_MASK>(b, 0.0);
+    double ap, bp;
+    if constexpr (ROW_MASK == 0xf) {
+      // every row takes part: a lane without a source reads zeros through bound_ctrl (no fill registers to set up);
+      // only the high word of the identity 1.0 needs one
+      const int z = 0;
+      bp = __hiloint2double(__builtin_amdgcn_update_dpp(z, __double2hiint(b), CTRL, ROW_MASK, 0xf, true),
+                            __builtin_amdgcn_update_dpp(z, __double2loint(b), CTRL, ROW_MASK, 0xf, true));
+      ap = __hiloint2double(__builtin_amdgcn_update_dpp(0x3ff00000, __double2hiint(a), CTRL, ROW_MASK, 0xf, false),
+                            __builtin_amdgcn_update_dpp(z, __double2loint(a), CTRL, ROW_MASK, 0xf, true));
+    } else {
+      ap = dpp_f64<CTRL, ROW_MASK>(a, 1.0);
+      bp = dpp_f64<CTRL, ROW_MASK>(b, 0.0);
+    }
     b = fma(a, bp, b);
     a *= ap;
   }

@@ -92,15 +92,24 @@ __device__ __forceinline__ float sbm_dpp(float v) {
 __device__ __forceinline__ float sbm_lane63f(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-// max over the wave of v >= 0 (NaN-free: callers map NaN to +inf first)
+// max over the wave of v >= 0 (NaN-free: callers map NaN to +inf first).  Non-negative floats order as their bit
+// patterns do, and an integer max takes the DPP operand itself: one v_max_i32_dpp per level where fmaxf costs a
+// v_mov_b32 for the fill, the DPP move, a canonicalising v_max_f32 and the max (6 instead of 30 instructions; the Newton
+// loops of the implicit kernels reduce once per iteration).  INT_MIN is the identity the masked-off rows keep.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int sbm_dpp_smax(int x) {
+  const int o = __builtin_amdgcn_update_dpp((int)0x80000000, x, CTRL, ROW_MASK, 0xf, false);
+  return x > o ? x : o;
+}
 __device__ __forceinline__ float sbm_wave_max(float v) {
-  v = fmaxf(v, sbm_dpp<0xb1, 0xf>(v));    // quad_perm:[1,0,3,2]
-  v = fmaxf(v, sbm_dpp<0x4e, 0xf>(v));    // quad_perm:[2,3,0,1]
-  v = fmaxf(v, sbm_dpp<0x124, 0xf>(v));   // row_ror:4
-  v = fmaxf(v, sbm_dpp<0x128, 0xf>(v));   // row_ror:8
-  v = fmaxf(v, sbm_dpp<0x142, 0xa>(v));   // row_bcast:15 -> rows 1, 3
-  v = fmaxf(v, sbm_dpp<0x143, 0xc>(v));   // row_bcast:31 -> rows 2, 3
-  return sbm_lane63f(v);
+  int x = __float_as_int(v);
+  x = sbm_dpp_smax<0xb1, 0xf>(x);    // quad_perm:[1,0,3,2]
+  x = sbm_dpp_smax<0x4e, 0xf>(x);    // quad_perm:[2,3,0,1]
+  x = sbm_dpp_smax<0x124, 0xf>(x);   // row_ror:4
+  x = sbm_dpp_smax<0x128, 0xf>(x);   // row_ror:8
+  x = sbm_dpp_smax<0x142, 0xa>(x);   // row_bcast:15 -> rows 1, 3
+  x = sbm_dpp_smax<0x143, 0xc>(x);   // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
 }
 __device__ __forceinline__ float sbm_wave_sumf(float v) {
   v += sbm_dpp<0xb1, 0xf>(v);
