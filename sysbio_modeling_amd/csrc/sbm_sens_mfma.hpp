@@ -14,7 +14,9 @@
 //   * J_y is handed over as a dense 16 RT x 16 RT tile image in LDS: row lane i drops its non-zeros at [i][column]
 //     (the rest stays zero), and every lane fetches its A operands A[i = l & 15][k = 4 s + (l >> 4)] from there --
 //     4 RT^2 loads of 8 bytes per stage, reused for all column tiles; the row stride is padded by two doubles, which
-//     makes the 32 lanes of an LDS access group hit 32 different bank pairs;
+//     makes the 32 lanes of an LDS access group hit 32 different bank pairs, and the rows of tile row rt are shifted
+//     by rt columns (the padding has room for RT - 1), so that the row lanes i and i + 16, which write the same column of a
+//     dense J_y at a distance of 16 x 34 doubles = 0 mod 32 bank pairs, do not collide either;
 //   * J_p is the C operand: the accumulators start from the dense [row][column] image the row lanes fill.
 //
 // Cost per stage: 4 RT^2 CT MFMAs of 64 cycles whatever the sparsity of J_y -- cascade20 (RT = 2, CT = 3): 48 MFMAs =
@@ -30,7 +32,7 @@ template <class M, int CT>
 struct SbmMfmaShared {
   static constexpr int RT = (M::NV + 15) / 16;
   static constexpr int MP = 16 * RT;               // padded rows (= padded k range)
-  static constexpr int LDJ = MP + 2;               // row stride of the J_y image: conflict-free A-operand reads
+  static constexpr int LDJ = MP + (RT > 3 ? 6 : 2);   // row stride of the J_y image (== 2 mod 4: conflict-free A-operand reads; >= MP + RT - 1)
   static constexpr int NC = 16 * CT;               // columns of this wavefront's chunk
   static constexpr int LDA = (NC % 32 == 16) ? NC : NC + 16;   // row stride of the J_p image: == 16 mod 32
   double Y[64];
@@ -94,7 +96,7 @@ struct MfmaSystem {
 #pragma unroll
       for (int kt = 0; kt < RT; ++kt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) aop[rt][kt][s] = sh->JD[(16 * rt + lr) * Sh::LDJ + 16 * kt + 4 * s + lq];
+        for (int s = 0; s < 4; ++s) aop[rt][kt][s] = sh->JD[(16 * rt + lr) * Sh::LDJ + 16 * kt + 4 * s + lq + rt];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(64, SbmMfmaPlan<M>::MIN_WAVES) sbm_sens_mfma_k
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJY; ++s) {
     const int c = M::rl_jycol(s, row);
-    sys.jdpos[s] = (has_row && c >= 0) ? row * Sh::LDJ + c : Sh::MP * Sh::LDJ + 1;       // else: spare slot
+    sys.jdpos[s] = (has_row && c >= 0) ? row * Sh::LDJ + c + (row >> 4) : Sh::MP * Sh::LDJ + 1;   // else: spare slot
   }
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJP; ++s) {
