@@ -213,13 +213,13 @@ def predict_explicit_pair(rtol, n_traj, chunks_dopri45=1, chunks_dop853=2, wave_
 
     with 2048 wave slots (1024 SIMDs x 2 resident wavefronts), steps 975 (rtol / 1e-9)^(-1/5) for DOPRI45 and
     172 (rtol / 1e-9)^(-1/8) for DOP853 (which the Python classes run at a tenth of an inherited rtol: the 172 includes
-    that), 1070 and 1544 VALU instructions per wavefront-step (PMC, profiles/).  At the default rtol DOP853 wins for every
+    that), 1052 and 1508 VALU instructions per wavefront-step (PMC, profiles/).  At the default rtol DOP853 wins for every
     batch size (1.9x with the chip full, 3.9x for a single vector); from rtol ~ 1e-6 up DOPRI45 does.  Returns
     ('dop853' | 'dopri45', predicted time ratio dopri45 / dop853)."""
     import math
     r = max(float(rtol), 1e-14) / 1e-9
-    t45 = math.ceil(max(int(n_traj), 1) * max(int(chunks_dopri45), 1) / wave_slots) * 975.0 * r ** (-1.0 / 5.0) * 1070.0
-    t853 = math.ceil(max(int(n_traj), 1) * max(int(chunks_dop853), 1) / wave_slots) * 172.0 * r ** (-1.0 / 8.0) * 1544.0
+    t45 = math.ceil(max(int(n_traj), 1) * max(int(chunks_dopri45), 1) / wave_slots) * 975.0 * r ** (-1.0 / 5.0) * 1052.0
+    t853 = math.ceil(max(int(n_traj), 1) * max(int(chunks_dop853), 1) / wave_slots) * 172.0 * r ** (-1.0 / 8.0) * 1508.0
     return ('dop853' if t853 < t45 else 'dopri45'), t45 / t853
 
 
