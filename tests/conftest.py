@@ -38,8 +38,10 @@ def check_parity(gpu, lsoda, tight=None, what='', criterion='survey'):
     t = tight() if callable(tight) else tight
     f = survey_err if criterion == 'survey' else parity_err
     eg, el = f(gpu, t), f(lsoda, t)
+    unit = ("units of SURVEY 8(d) incl. this build's block floor (1e-12 of the block's largest entry, oracle/tolerances.py)"
+            if criterion == 'survey' else "units of 1e-8 |ref| + 5e-9")
     assert eg <= 1.0 and el > eg, ("%s: %.2f tolerance units off the reference's LSODA; against a tight solution the GPU "
-                                   "is %.2f units off and LSODA %.2f" % (what, e, eg, el))
+                                   "is %.2f and LSODA %.2f %s" % (what, e, eg, el, unit))
     return e, eg
 
 
