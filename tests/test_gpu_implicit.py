@@ -284,6 +284,38 @@ def test_stiff_integrator_on_35_reference_vectors_spread_over_the_ensemble(gpu_m
     print("fixed 4096 + 8192 Richardson pair on the 35 vectors: worst sensitivity error vs tight %.2f units" % ef)
 
 
+def test_stiff_integrator_at_full_size_is_batch_independent(gpu_models, golden):
+    """BASELINE configs[4] at its full size -- all 4096 vectors of the stiff50 ensemble, 2550 ODEs each, one launch at default
+    options -- through properties that need no reference: every vector integrates (status 0, finite rows); the launch
+    is deterministic; a vector's rows do not depend on the batch it travels in or on its place in it (the ensemble in
+    reverse order, the 35 pinned vectors on their own: bit for bit the rows of the big launch -- so the parity shown on the
+    35 holds for them inside the full-size pass as well)."""
+    from sysbio_modeling_amd import models_zoo
+    m = gpu_models('stiff50')
+    _, P = models_zoo.stiff_ensemble(4096, n=50)
+    g = golden('stiff50_wide_ref.npz')
+    t_out = _from_zero(g['t'][g['idx']])
+    kw = dict(method='implicit_controlled')
+    S, Y = m.calc_jacobian_batch(P, t_out, return_states=True, **kw)
+    steps = m.last_info['n_steps'].copy()
+    assert not m.last_info['status'].any()
+    assert np.isfinite(Y).all() and np.isfinite(S).all()
+    assert steps.min() > 50 and steps.max() < 5 * np.median(steps)
+    S2, Y2 = m.calc_jacobian_batch(P, t_out, return_states=True, **kw)
+    assert np.array_equal(S2, S) and np.array_equal(Y2, Y)
+    del S2, Y2
+    Sr, Yr = m.calc_jacobian_batch(P[::-1].copy(), t_out, return_states=True, **kw)
+    assert np.array_equal(Sr[::-1], S) and np.array_equal(Yr[::-1], Y)
+    del Sr, Yr
+    idx = np.concatenate([[0, 1, 2], g['index']])
+    assert np.array_equal(P[g['index']], g['P'])
+    Sp, Yp = m.calc_jacobian_batch(P[idx], t_out, return_states=True, **kw)
+    assert np.array_equal(Sp, S[idx]) and np.array_equal(Yp, Y[idx])
+    assert np.array_equal(m.last_info['n_steps'], steps[idx])
+    # initial rows: the initial condition (zeros) exactly
+    assert not Y[:, 0].any() and not S[:, 0].any()
+
+
 def test_romberg_controlled_implicit_needs_no_step_count(gpu_models, golden):
     """method='implicit_romberg': the round-1 host loop around the fixed-step kernel -- the step count is found by
     doubling until two successive Richardson extrapolants agree (sysbio_modeling_amd/_control.py).  With default
