@@ -1,8 +1,10 @@
-"""emit_implicit.py on the host: the generated header of a model is plain C++ once the device qualifiers and the few
-macros of csrc/sbm_integrators.hpp are defined away, so the triangular-solve members can be compiled with g++ and
-called through ctypes -- no GPU.  Checked here, on random lower-triangular networks with several sub-diagonal entries
-and several J_p entries per row (patterns the zoo models do not have):
+"""The generated HIP header on the host: it is plain C++ once the device qualifiers and the few macros of
+csrc/sbm_integrators.hpp are defined away, so its members can be compiled with g++ and called through ctypes -- no GPU.
+Checked here, on random networks (lower-triangular ones with several sub-diagonal entries and several J_p entries per
+row -- patterns the zoo models do not have -- and general ones with feedback):
 
+  * the row-lane form (emit_rowlane.py: class bodies + operand / result tables) reproduces f, J_y and J_p of the generated
+    Python model;
   * ``im_sens_tri`` (the fused sensitivity step of csrc/sbm_implicit_extrap.hpp: J_p pick next to the substitution, tables
     loaded a block of rows ahead) returns BIT FOR BIT what the two-pass form it replaced returns -- the J_p pick of
     sbm_implicit_stepper.hpp::sens_euler followed by ``im_solve_tri`` -- for every sensitivity column and for a lane
@@ -77,6 +79,19 @@ void solve_tri_pick(const double* mf, const double* g, int lane, double* d_out) 
   M::im_solve_tri_pick<RPL>(mf, g, lane, d);
   for (int r = 0; r < RPL; ++r) d_out[r] = d[r];
 }
+// what row lane `row` evaluates: operands gathered through the row-lane tables, one class body
+void eval_row(int row, double t, const double* y, const double* p, double* f, double* jy, double* jp) {
+  double ys[M::RL_MAXYS], ps[M::RL_MAXPS], jyo[M::RL_MAXJY], jpo[M::RL_MAXJP];
+  for (int s = 0; s < M::RL_MAXYS; ++s) ys[s] = y[M::rl_ys(s, row)];
+  for (int s = 0; s < M::RL_MAXPS; ++s) ps[s] = p[M::rl_ps(s, row)];
+  for (int s = 0; s < M::RL_MAXJY; ++s) jyo[s] = 0.0;
+  for (int s = 0; s < M::RL_MAXJP; ++s) jpo[s] = 0.0;
+  double ff = 0.0;
+  M::class_dispatch(M::rl_class(row), t, ys, ps, ff, jyo, jpo);
+  *f = ff;
+  for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = jyo[s];
+  for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = jpo[s];
+}
 void build_factor_solve(double gamma, const double* jy, double* b_io) {
   double m[M::IM_NM], b[M::NV];
   M::im_build(gamma, jy, m);
@@ -138,6 +153,7 @@ def _host_library(gm, tmp_path):
     lib.solve_tri.argtypes = [dp, dp]
     lib.solve_tri_pick.argtypes = [dp, dp, ctypes.c_int, dp]
     lib.build_factor_solve.argtypes = [ctypes.c_double, dp, dp]
+    lib.eval_row.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp, dp, dp, dp]
     for f in ('jpcol', 'mfpos', 'jycol'):
         getattr(lib, f).argtypes = [ctypes.c_int, ctypes.c_int]
     for f in ('rstart', 'diagslot'):
@@ -220,3 +236,53 @@ def test_triangular_factors_solve_the_newton_matrix(tmp_path, seed, n):
         for r in range(rpl):
             if lane + 64 * r < n:
                 assert dd[r] == x2[lane + 64 * r]
+
+
+def _general_network(seed, n):
+    """tests/test_gpu_user_models.py::_random_network: feedback, saturation, product inhibition -- not triangular"""
+    from tests.test_gpu_user_models import _random_network
+    return _random_network(seed, n)
+
+
+@pytest.mark.parametrize('make,seed,n', [(_triangular_network, 3, 24), (_general_network, 2, 11), (_general_network, 4, 30)])
+def test_row_lane_tables_reproduce_the_right_hand_side(tmp_path, make, seed, n):
+    """The row-lane form every kernel evaluates (emit_rowlane.py: isomorphic equations share one class body, operands
+    come through the tables SBM_RL_YS / PS, results go out through JYOUT / JYCOL / JPCOL) against the generated Python
+    model the oracle integrates: f, every non-zero of J_y and of J_p, and nothing else."""
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    gm = GeneratedModel(make(seed, n))
+    lib = _host_library(gm, tmp_path)
+    k, n_par = gm.n_sens, len(gm.param_order)
+    assert lib.nv() == n and lib.nk() == k
+    rng = np.random.default_rng(seed)
+    y = rng.uniform(0.2, 2.0, n)
+    p = rng.uniform(0.3, 3.0, n_par)
+    t = 0.7
+    f_ref = np.zeros(n)
+    gm.model(y, t, f_ref, p)
+    aug, out = np.zeros(n + n * k), np.zeros(n + n * k)
+    aug[:n] = y
+    gm.sens_model(aug, t, out, p)
+    Jp_ref = out[n:].reshape(n, k)
+    jac = np.zeros((n, n))
+    gm.model_jac(y, t, jac, p)
+    Jy_ref = jac.T                                   # jacout[b, a] = d f_a / d y_b
+    maxjy, maxjp = lib.maxjy(), lib.maxjp()
+    Jy, Jp = np.zeros((n, n)), np.zeros((n, k))
+    f = np.zeros(n)
+    for i in range(n):
+        fi, jy, jp = np.zeros(1), np.zeros(maxjy), np.zeros(maxjp)
+        lib.eval_row(i, t, _p(y), _p(p), _p(fi), _p(jy), _p(jp))
+        f[i] = fi[0]
+        for s in range(maxjy):
+            c = lib.jycol(s, i)
+            if c >= 0:
+                Jy[i, c] += jy[s]
+        for s in range(maxjp):
+            c = lib.jpcol(s, i)
+            if c >= 0:
+                Jp[i, c] += jp[s]
+    assert np.allclose(f, f_ref, rtol=1e-12, atol=1e-14)
+    assert np.allclose(Jy, Jy_ref, rtol=1e-12, atol=1e-14)
+    assert np.allclose(Jp, Jp_ref, rtol=1e-12, atol=1e-14)
+    assert np.count_nonzero(Jy_ref) > n and np.count_nonzero(Jp_ref) >= n
