@@ -2,9 +2,13 @@
 patterns: the redundant and the row-distributed LU of the implicit stepper, not the chain prefix -- integrated with
 method='auto' (DOPRI45 with a budget, then the stiff integrator SBM_IMPLICIT_EXTRAP) and with the stiff integrator
 directly, against odeint with the generated analytic Jacobian (LSODA switches to BDF).  One line per network; exits
-non-zero when a result is off by more than 1.5 tolerance units.  Record of the last run: profiles/r03/stiff_network_sweep.txt
+non-zero when a result is off by more than 1.5 tolerance units.  Records of the last runs: profiles/r03/stiff_network_sweep.txt, stiff_tri_network_sweep.txt
 
-    python tests/tools/stiff_network_sweep.py [n_networks]        (GPU box; compiles one plugin per network)"""
+    python tests/tools/stiff_network_sweep.py [n_networks] [tri]     (GPU box; compiles one plugin per network)
+
+``tri``: lower-triangular networks instead (tests/test_generated_header_host.py::_triangular_network: several sub-diagonal
+entries and several J_p entries per row) -- the fused substitution forms of emit_implicit.py (im_solve_tri_pick for the
+Newton update, im_sens_tri for the sensitivity step of SBM_IMPLICIT_EXTRAP) on patterns the zoo does not have."""
 import os, sys, time, warnings
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -15,18 +19,23 @@ from sysbio_modeling_amd.model import OdeModel
 from oracle import odeint_oracle as oo
 
 n_models = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+triangular = len(sys.argv) > 2 and sys.argv[2] == 'tri'
+if triangular:
+    from tests.test_generated_header_host import _triangular_network
 rng0 = np.random.default_rng(777)
 worst = 0.0
 for k in range(n_models):
     seed, n = int(rng0.integers(10, 10000)), int(rng0.integers(4, 16))
-    gm = GeneratedModel(_random_network(seed, n))
+    if triangular:
+        n += 8
+    gm = GeneratedModel(_triangular_network(seed, n) if triangular else _random_network(seed, n))
     m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=gm.spec.name)
     rng = np.random.default_rng(seed)
     names = list(gm.param_order)
     P = np.exp(rng.uniform(np.log(0.2), np.log(2.0), (3, len(names))))
     fast = [i for i in range(n) if i % 3 == 1]
     for i in fast:                                     # fast species: production and degradation x 1e4
-        for nm in ('d%d' % i, 'k%d' % i):
+        for nm in ('d%d' % i, 'k%d' % i, 'k%d_0' % i, 'k%d_1' % i):
             if nm in names:
                 P[:, names.index(nm)] *= 1e4
     t = np.linspace(0, 20.0, 1000); idx = np.array([0, 333, 999])
