@@ -68,13 +68,13 @@ def main():
     print("implicit midpoint (graded start) + Richardson: %6d steps per vector, %.3f s" % (n_im, dt_im))
     print("DOPRI45 (explicit):             %6d steps per vector, %.3f s" % (n_ex, dt_ex))
     print("largest difference between the two sensitivity tables: %.1e (relative)" % err)
-    # no step count to pick: error control inside the kernel (three nested solutions, passive Richardson) ...
+    # no step count to pick: local error control inside the kernel (extrapolated implicit Euler, SBM_IMPLICIT_EXTRAP) ...
     t0 = time.time()
     S_c = m.calc_jacobian_batch(P, t, method='implicit_controlled', rtol=1e-7, atol=1e-10)
     dt_c = time.time() - t0
     i = m.last_info
     err_c = np.max(np.abs(S_c - S_ex) / (np.abs(S_ex) + 1e-3 * np.abs(S_ex).max()))
-    print("implicit, controlled (rtol 1e-7): %6d coarse steps per vector (+%d in abandoned passes), %.3f s, difference to "
+    print("implicit, controlled (rtol 1e-7): %6d macro steps per vector (+%d rejected), %.3f s, difference to "
           "DOPRI45 %.1e" % (int(i['n_steps'].mean()), int(i['n_rejected'].mean()), dt_c, err_c))
     # ... and what LSODA does for the reference: explicit first, implicit for the vectors that exhaust the budget
     t0 = time.time()
