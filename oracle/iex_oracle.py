@@ -99,9 +99,13 @@ def jacobians_from(gm, use_c=True):
 
 
 def integrate(gm, p, t_out, rtol=3e-9, atol=3e-12, order=0, t0=0.0, y0=None, s0=None, with_sens=True, h0=0.0,
-              max_steps=200000, use_c=True):
+              max_steps=200000, use_c=True, predictor=None):
     """Returns (Y (len(t_out), n), S (len(t_out), n*k) or None, info) with info = dict(n_steps, n_reject, n_eval,
-    n_euler, status); status as the kernel's: 0 ok, 1 max_steps, 3 step_underflow."""
+    n_euler, status); status as the kernel's: 0 ok, 1 max_steps, 3 step_underflow.
+
+    ``predictor`` (experiments only, scripts/dev_iex_predictor.py; the kernel has no such thing): callable
+    (j, m, h, Hs, y_n, ya, default, previous_sequence_states) -> Newton's starting point of step m of sequence j, in place
+    of ``default`` (the polynomial through the sequence's own last points)."""
     n, k = gm.n_vars, gm.n_sens
     p = np.ascontiguousarray(p, dtype=np.float64)
     fjac = jacobians_from(gm, use_c)
@@ -167,10 +171,12 @@ def integrate(gm, p, t_out, rtol=3e-9, atol=3e-12, order=0, t0=0.0, y0=None, s0=
             zh = np.zeros((n, k))
             ze = np.zeros((n, k))
             ok = True
+            prev_pts = []
             for j in range(1, K + 1):
                 h = Hs / j
                 ya, yp, yp2, yp3 = y.copy(), y - h * ydot, np.zeros(n), np.zeros(n)
                 Sj = S.copy()
+                pts = []
                 for m in range(j):
                     if m < 2:
                         yb = 2.0 * ya - yp
@@ -178,15 +184,19 @@ def integrate(gm, p, t_out, rtol=3e-9, atol=3e-12, order=0, t0=0.0, y0=None, s0=
                         yb = 3.0 * (ya - yp) + yp2
                     else:
                         yb = 4.0 * (ya + yp2) - 6.0 * yp - yp3
+                    if predictor is not None:
+                        yb = predictor(j, m, h, Hs, y, ya, yb, prev_pts)
                     ok, yb, M, Jp = newton(t + (m + 1) * h, h, ya, yb, natol)
                     if not ok:
                         break
+                    pts.append(yb)
                     yp3, yp2, yp, ya = yp2, yp, ya, yb
                     info['n_euler'] += 1
                     if with_sens:
                         Sj = np.linalg.solve(M, Sj + h * Jp)
                 if not ok:
                     break
+                prev_pts = pts
                 yh += wh[j] * (ya - y)
                 ye += we[j] * (ya - y)
                 if with_sens:
