@@ -10,7 +10,8 @@ row -- patterns the zoo models do not have -- and general ones with feedback):
     sbm_implicit_stepper.hpp::sens_euler followed by ``im_solve_tri`` -- for every sensitivity column and for a lane
     without one;
   * ``im_solve_tri`` with the factors ``im_build`` / ``im_factor`` produce solves (I - gamma J_y) x = b (numpy);
-  * ``im_solve_tri_pick`` hands lane i component i of the same solution.
+  * ``im_solve_tri_pick`` hands lane i component i of the same solution;
+  * the symbolic LU of a NON-triangular J_y (fill-in worked out at generation time) solves its Newton matrix.
 
 The GPU tests exercise these members inside the kernels on the zoo's patterns (tests/test_gpu_implicit.py)."""
 import ctypes
@@ -286,3 +287,34 @@ def test_row_lane_tables_reproduce_the_right_hand_side(tmp_path, make, seed, n):
     assert np.allclose(Jy, Jy_ref, rtol=1e-12, atol=1e-14)
     assert np.allclose(Jp, Jp_ref, rtol=1e-12, atol=1e-14)
     assert np.count_nonzero(Jy_ref) > n and np.count_nonzero(Jp_ref) >= n
+
+
+@pytest.mark.parametrize('seed,n', [(2, 11), (3, 17), (4, 30)])
+def test_symbolic_lu_with_fill_in_solves_the_newton_matrix(tmp_path, seed, n):
+    """Networks with feedback: J_y is not triangular, the elimination worked out at generation time (symbolic_lu:
+    natural order, fill-in entries added to the pattern) is straight-line code in im_factor / im_solve -- against numpy
+    on (I - gamma J_y) x = b, for a mild and a stiff gamma."""
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    gm = GeneratedModel(_general_network(seed, n))
+    lib = _host_library(gm, tmp_path)
+    assert lib.is_tri() == 0 and lib.has_fused() == 0
+    d = gm.derived
+    assert lib.im_nm() >= lib.njy()
+    fill_in = lib.im_nm() - lib.njy()
+    assert fill_in > 0 or n < 30, fill_in             # the largest network does have fill-in
+    rng = np.random.default_rng(seed)
+    jy = rng.standard_normal(lib.njy())
+    J = np.zeros((n, n))
+    for i in range(n):
+        for e, c in d.jy_rows[i]:
+            J[i, c] = jy[e]
+    for gamma in (0.05, 40.0):
+        Mx = np.eye(n) - gamma * J
+        b0 = rng.standard_normal(n)
+        x = b0.copy()
+        lib.build_factor_solve(gamma, _p(np.concatenate([jy, [0.0, 0.0]])), _p(x))
+        x_ref = np.linalg.solve(Mx, b0)
+        # no pivoting (the Newton matrices of the implicit integrators are diagonally dominant for the steps they take;
+        # a random J at gamma = 40 is not): judged by the residual relative to the conditioning
+        scale = np.linalg.cond(Mx) * 1e-13
+        assert np.allclose(x, x_ref, rtol=max(1e-10, scale), atol=max(1e-12, scale * np.abs(x_ref).max())), gamma
