@@ -236,3 +236,37 @@ def test_normalized_loss_function():
     res = SquareLossFunction().residuals(sim, measures)
     norm = NormalizedSquareLossFunction().residuals(sim, measures)
     assert np.allclose(norm * measures['mean'], res)
+
+
+def test_log_scale_factor_against_the_real_reference_class(golden):
+    """tests/golden/log_scale_factor_ref.npz holds what the REAL reference LogScaleFactor returns on random inputs (the one
+    class of the assembly half that runs here as it stands: make_golden_log_scale_factor.py).  The same inputs as frames
+    through LogSquareLossFunction on the device (sbm_loss_eval_host -> k_assemble): the scale factor, the data rows of
+    the Jacobian J / sim + (dB/dtheta) / B and, where the case has one, the prior's residual and Jacobian row."""
+    g = golden('log_scale_factor_ref.npz')
+    for c in range(int(g['n_cases'])):
+        sim_v, data, std, jm = (g['%s_%d' % (k, c)] for k in ('sim', 'data', 'std', 'jac'))
+        sf_ref, grad_ref, prior = float(g['sf_%d' % c]), g['sf_gradient_%d' % c], g['prior_%d' % c]
+        n, q = jm.shape
+        idx = [('Experiment 1', 'M')] * n
+        sim = pd.DataFrame({'mean': sim_v, 'timecourse': np.arange(n, dtype=float)})
+        measures = pd.DataFrame({'mean': data, 'std': std, 'timecourse': np.arange(n, dtype=float)})
+        has_prior = bool(np.isfinite(prior[0]))
+        lf = LogSquareLossFunction(sf_groups=['M'])
+        if has_prior:
+            lf.set_scale_factor_priors('M', float(prior[0]), float(prior[1]))
+            idx = idx + [("~~SF_Prior", "~M")]
+            sim = pd.concat([sim, pd.DataFrame({'mean': [float(prior[0])], 'timecourse': [np.nan]})], ignore_index=True)
+            measures = pd.concat([measures, pd.DataFrame({'mean': [float(prior[0])], 'std': [float(prior[1])],
+                                                          'timecourse': [np.nan]})], ignore_index=True)
+            jm = np.vstack([jm, np.zeros((1, q))])
+        sim.index = measures.index = pd.MultiIndex.from_tuples(idx)
+        res = lf.residuals(sim, measures)
+        assert lf.scale_factors['M'].sf == pytest.approx(sf_ref, rel=1e-12), c
+        assert np.allclose(res.values[:n], (np.log(sf_ref * sim_v) - np.log(data)) / std, rtol=1e-9, atol=1e-9), c   # (:56-64: / std)
+        jac = lf.jacobian(sim, measures, pd.DataFrame(jm, columns=['p%d' % j for j in range(q)], index=sim.index))
+        rows_ref = g['jac_%d' % c] / sim_v[:, None] + (grad_ref / sf_ref)[None, :]
+        assert np.allclose(jac.values[:n], rows_ref, rtol=1e-10, atol=1e-12 * np.abs(rows_ref).max()), c
+        if has_prior:
+            assert res.values[-1] == pytest.approx(float(g['prior_residual_%d' % c]), rel=1e-10, abs=1e-12), c
+            assert np.allclose(jac.values[-1], g['prior_gradient_%d' % c], rtol=1e-10, atol=1e-13), c

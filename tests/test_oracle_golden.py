@@ -298,3 +298,35 @@ def test_normalized_loss_identity():
     norm = _RowsOnlyOracle(nrows, sims_nz, None, [], 1).residuals(np.zeros(1))
     d = np.array([r[2] for r in rows])
     assert np.allclose(norm * d, plain)
+
+
+def _log_sf_cases(golden):
+    g = golden('log_scale_factor_ref.npz')
+    for c in range(int(g['n_cases'])):
+        yield c, {k: g['%s_%d' % (k, c)] for k in ('sim', 'data', 'std', 'jac', 'prior', 'sf', 'sf_gradient',
+                                                    'prior_residual', 'prior_gradient')}
+
+
+def test_log_scale_factor_restatement_equals_the_real_reference_class(golden):
+    """The one class of the assembly half that runs here as it stands -- the reference's LogScaleFactor (needs numpy
+    only; tests/golden/make_golden_log_scale_factor.py) -- against the oracle's restatement of it
+    (project_oracle.py::_sf, log branch; the prior row of residuals / calc_project_jacobian): scale factor, its gradient,
+    the prior residual and the prior's Jacobian row to rounding, on six random cases."""
+    for c, g in _log_sf_cases(golden):
+        n, q = g['jac'].shape
+        rows = [(0, 'M', d, s, float(i)) for i, (d, s) in enumerate(zip(g['data'], g['std']))]
+        po = _RowsOnlyOracle(rows, g['sim'], g['jac'], ['M'], q)
+        po.loss = 'log'
+        B, dB, _, _, _ = po._sf(rows, g['sim'], g['jac'])
+        assert B[0] == pytest.approx(float(g['sf']), rel=1e-13), c
+        assert np.allclose(dB[0], g['sf_gradient'], rtol=1e-12, atol=1e-15 * np.abs(g['sf_gradient']).max()), c
+        if np.isfinite(g['prior'][0]):
+            po.sf_priors = {0: (float(g['prior'][0]), float(g['prior'][1]))}
+            res = po.residuals(np.zeros(q))
+            assert res[-1] == pytest.approx(float(g['prior_residual']), rel=1e-12, abs=1e-14), c
+            Jp = po.calc_project_jacobian(np.zeros(q))
+            assert np.allclose(Jp[-1], g['prior_gradient'], rtol=1e-12, atol=1e-15), c      # reference_compat row: (dB/dtheta)/B
+            # the data rows of the log loss: J / sim + (dB/dtheta) / B   (log_squared_loss_function.py:92-93)
+            assert np.allclose(Jp[:-1], g['jac'] / g['sim'][:, None] + (g['sf_gradient'] / float(g['sf']))[None, :], rtol=1e-12)
+        else:
+            assert np.isnan(g['prior_residual'])
