@@ -330,3 +330,42 @@ def test_log_scale_factor_restatement_equals_the_real_reference_class(golden):
             assert np.allclose(Jp[:-1], g['jac'] / g['sim'][:, None] + (g['sf_gradient'] / float(g['sf']))[None, :], rtol=1e-12)
         else:
             assert np.isnan(g['prior_residual'])
+
+
+def test_experiment_and_measurement_containers_equal_the_real_reference_classes(golden):
+    """experiment/experiments.py and measurement/timecourse_measurement.py run here as they stand
+    (tests/golden/make_golden_containers.py recorded what the reference's objects answer on random measurement sets); this
+    package's Experiment / TimecourseMeasurement on the same inputs: the order the measurements are kept in, the default
+    error bars, get_unique_timepoints with and without zero, get_nonzero_measurements, drop_timepoint_zero of one variable
+    and of all."""
+    g = golden('containers_ref.npz')
+    for c in range(int(g['n_cases'])):
+        names = [str(x) for x in g['names_%d' % c]]
+        ms = []
+        for j, nm in enumerate(names):
+            s = g['s_%d_%d' % (c, j)]
+            ms.append(TimecourseMeasurement(nm, g['v_%d_%d' % (c, j)].copy(), g['t_%d_%d' % (c, j)].copy(),
+                                            None if np.isnan(s).all() else s.copy()))
+        e = Experiment('Exp%d' % c, ms)
+        assert [m.variable_name for m in e.measurements] == [str(x) for x in g['order_%d' % c]]
+        assert np.array_equal(e.get_unique_timepoints(), g['unique_%d' % c])
+        assert np.array_equal(e.get_unique_timepoints(include_zero=True), g['unique0_%d' % c])
+        for j, m in enumerate(e.measurements):
+            assert np.array_equal(np.asarray(m.std, dtype=float), g['std_%d_%d' % (c, j)])
+            v, s, t = m.get_nonzero_measurements()
+            assert np.array_equal(v, g['nz_v_%d_%d' % (c, j)]) and np.array_equal(s, g['nz_s_%d_%d' % (c, j)]) \
+                and np.array_equal(t, g['nz_t_%d_%d' % (c, j)])
+        e.drop_timepoint_zero(e.measurements[0].variable_name)
+        for j, m in enumerate(e.measurements):
+            assert np.array_equal(np.asarray(m.timepoints, dtype=float), g['d1_t_%d_%d' % (c, j)])
+        e.drop_timepoint_zero()
+        for j, m in enumerate(e.measurements):
+            assert np.array_equal(np.asarray(m.timepoints, dtype=float), g['d2_t_%d_%d' % (c, j)])
+            assert np.array_equal(np.asarray(m.values, dtype=float), g['d2_v_%d_%d' % (c, j)])
+        assert np.array_equal(e.get_unique_timepoints(include_zero=True), g['unique_after_%d' % c])
+    with pytest.raises(KeyError):                      # experiments.py:131-134: one timeseries per variable
+        Experiment('E', [TimecourseMeasurement('a', np.ones(2), np.arange(2.0)), TimecourseMeasurement('a', np.ones(2), np.arange(2.0))])
+    with pytest.raises(ValueError):                    # abstract_measurement.py:16-17
+        TimecourseMeasurement('a', np.ones(2), np.arange(2.0), np.array([1.0, 0.0]))
+    with pytest.raises(ValueError):                    # experiments.py:33-36
+        Experiment('_x', [TimecourseMeasurement('a', np.ones(2), np.arange(2.0))])
