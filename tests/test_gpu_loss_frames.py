@@ -270,3 +270,31 @@ def test_log_scale_factor_against_the_real_reference_class(golden):
         if has_prior:
             assert res.values[-1] == pytest.approx(float(g['prior_residual_%d' % c]), rel=1e-10, abs=1e-12), c
             assert np.allclose(jac.values[-1], g['prior_gradient_%d' % c], rtol=1e-10, atol=1e-13), c
+
+
+def test_scale_factor_grouping_against_the_real_reference_base_class(golden):
+    """tests/golden/loss_grouping_ref.npz: the REAL reference LossFunctionWithScaleFactors + LogScaleFactor on random frames
+    (several experiments, measures that share a scale factor, measures without one, a prior row;
+    make_golden_loss_grouping.py).  The same frames through LogSquareLossFunction on the device: every group's factor and
+    the residuals (log(scaled sim) - log(data)) / std built from the reference's scaled simulations, the prior row
+    (log B - prior) / sigma."""
+    g = golden('loss_grouping_ref.npz')
+    for c in range(int(g['n_cases'])):
+        exp, mea = [str(x) for x in g['exp_%d' % c]], [str(x) for x in g['measure_%d' % c]]
+        groups = [frozenset(str(x).split('|')) if '|' in str(x) else str(x) for x in g['groups_%d' % c]]
+        prior = g['prior_%d' % c]
+        idx = pd.MultiIndex.from_tuples(list(zip(exp, mea)))
+        sim = pd.DataFrame({'mean': g['sim_%d' % c], 'timecourse': g['time_%d' % c]}, index=idx)
+        measures = pd.DataFrame({'mean': g['data_%d' % c], 'std': g['std_%d' % c], 'timecourse': g['time_%d' % c]}, index=idx)
+        lf = LogSquareLossFunction(sf_groups=groups)
+        data_rows = np.array([not e.startswith('~~') for e in exp])
+        if np.isfinite(prior[0]):
+            lf.set_scale_factor_priors(groups[0], float(prior[0]), float(prior[1]))
+        res = lf.residuals(sim, measures)
+        for gi, grp in enumerate(groups):
+            assert lf.scale_factors[grp].sf == pytest.approx(float(g['sf_%d' % c][gi]), rel=1e-12), (c, grp)
+        ref = (np.log(g['scaled_%d' % c][data_rows]) - np.log(g['data_%d' % c][data_rows])) / g['std_%d' % c][data_rows]
+        assert np.allclose(res.values[data_rows], ref, rtol=1e-9, atol=1e-10), c
+        if np.isfinite(prior[0]):
+            log_b = g['after_prior_update_%d' % c][~data_rows][0]
+            assert res.values[~data_rows][0] == pytest.approx((log_b - prior[0]) / prior[1], rel=1e-10, abs=1e-12), c

@@ -369,3 +369,38 @@ def test_experiment_and_measurement_containers_equal_the_real_reference_classes(
         TimecourseMeasurement('a', np.ones(2), np.arange(2.0), np.array([1.0, 0.0]))
     with pytest.raises(ValueError):                    # experiments.py:33-36
         Experiment('_x', [TimecourseMeasurement('a', np.ones(2), np.arange(2.0))])
+
+
+def _grouping_cases(golden):
+    g = golden('loss_grouping_ref.npz')
+    for c in range(int(g['n_cases'])):
+        d = {k: g['%s_%d' % (k, c)] for k in ('exp', 'measure', 'sim', 'data', 'std', 'time', 'groups', 'prior', 'sf',
+                                               'scaled', 'after_prior_update')}
+        d['groups'] = [str(x).split('|') for x in d['groups']]
+        yield c, d
+
+
+def test_scale_factor_grouping_equals_the_real_reference_base_class(golden):
+    """abstract_loss_function.py::LossFunctionWithScaleFactors -- the class that decides which rows of which experiments
+    enter which scale factor, lets measures share one, applies the factors and fills the prior row -- runs here as it
+    stands, with the real LogScaleFactor (tests/golden/make_golden_loss_grouping.py).  The oracle's restatement on the
+    same frames: every group's factor, the scaled simulations, log B in the prior row."""
+    for c, g in _grouping_cases(golden):
+        data_rows = np.array([not str(e).startswith('~~') for e in g['exp']])
+        exps = {}
+        rows = [(exps.setdefault(str(e), len(exps)), str(m), d, s, t) for e, m, d, s, t in
+                zip(g['exp'][data_rows], g['measure'][data_rows], g['data'][data_rows], g['std'][data_rows], g['time'][data_rows])]
+        po = _RowsOnlyOracle(rows, g['sim'][data_rows], None, [tuple(x) if len(x) > 1 else x[0] for x in g['groups']], 1)
+        po.loss = 'log'
+        B, _, grp, _, _ = po._sf(rows, g['sim'][data_rows])
+        assert np.allclose(B, g['sf'], rtol=1e-13), c
+        scaled = g['sim'][data_rows] * np.where(grp >= 0, B[np.clip(grp, 0, None)], 1.0)
+        assert np.allclose(scaled, g['scaled'][data_rows], rtol=1e-13), c
+        # rows of measures outside every group are left alone
+        assert np.array_equal(scaled[grp < 0], g['sim'][data_rows][grp < 0])
+        if np.isfinite(g['prior'][0]):
+            po.sf_priors = {0: (float(g['prior'][0]), float(g['prior'][1]))}
+            res = po.residuals(np.zeros(1))
+            log_b = g['after_prior_update'][~data_rows][0]            # what the reference wrote into the prior row
+            assert log_b == pytest.approx(np.log(g['sf'][0]), rel=1e-13)
+            assert res[-1] == pytest.approx((log_b - g['prior'][0]) / g['prior'][1], rel=1e-12, abs=1e-14), c
