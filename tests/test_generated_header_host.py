@@ -318,3 +318,41 @@ def test_symbolic_lu_with_fill_in_solves_the_newton_matrix(tmp_path, seed, n):
         # a random J at gamma = 40 is not): judged by the residual relative to the conditioning
         scale = np.linalg.cond(Mx) * 1e-13
         assert np.allclose(x, x_ref, rtol=max(1e-10, scale), atol=max(1e-12, scale * np.abs(x_ref).max())), gamma
+
+
+def _hub_network(n=14, fan_in=11):
+    """a lower-triangular network whose last species is produced from ``fan_in`` earlier ones with one shared rate constant:
+    one row of the table is wider than a whole block of im_sens_tri (8 doubles)"""
+    import sympy
+    from sysbio_modeling_amd.symbolic.emit import ModelSpec
+    xs = [sympy.Symbol('x%d' % i) for i in range(n)]
+    params, eq = [], OrderedDict()
+    for i in range(n):
+        params += ['d%d' % i, 'k%d' % i]
+        d, k = sympy.Symbol('d%d' % i), sympy.Symbol('k%d' % i)
+        if i == 0:
+            rhs = k - d * xs[0]
+        elif i < n - 1:
+            rhs = k * xs[i - 1] - d * xs[i]
+        else:
+            rhs = k * sum(xs[j] for j in range(fan_in)) - d * xs[i]
+        eq['x%d' % i] = rhs
+    return ModelSpec(name='hub%d_%d' % (n, fan_in), variables=[str(x) for x in xs], params=params, equations=eq)
+
+
+def test_fused_sensitivity_step_with_a_row_wider_than_a_block(tmp_path):
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    gm = GeneratedModel(_hub_network())
+    lib = _host_library(gm, tmp_path)
+    n, n_mf, maxjp = lib.nv(), lib.im_mf(), lib.maxjp()
+    assert lib.is_tri() == 1 and lib.has_fused() == 1
+    wide = max(sum(1 for s in range(lib.maxjy()) if 0 <= lib.mfpos(s, i) < n_mf) for i in range(n))
+    assert wide >= 11
+    rng = np.random.default_rng(3)
+    mf, ja = rng.standard_normal(n_mf + 2), rng.standard_normal(n * maxjp + 2)
+    for col in range(lib.nk()):
+        z0 = rng.standard_normal(n)
+        a, b = z0.copy(), z0.copy()
+        lib.two_pass(_p(mf), _p(ja), 0.11, col, _p(a))
+        lib.fused(_p(mf), _p(ja), 0.11, col, _p(b))
+        assert np.array_equal(a, b), col
