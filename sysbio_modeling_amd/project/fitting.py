@@ -87,10 +87,13 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     tenth of the cost) to get its residuals; the state + sensitivity system is integrated only at the trial points that
     were accepted -- MINPACK's economy (lmder evaluates the Jacobian once per successful step, the function once per
     trial), batched: about half of the trials are rejected on a sloppy problem.  ``False``: one state + sensitivity
-    integration of every trial point per iteration.  'auto' (default): lazy from 8192 trajectories per iteration on (starts x
-    experiments) -- below that the chip is not full, a launch lasts as long as its longest trajectory whatever their
-    number, and two launches per iteration cost more than one (measured on the configs[3] project: 256 starts x 8
-    experiments 0.86 s eager / 0.97 s lazy per 100 iterations; see DESIGN.md section 6 for larger batches).
+    integration of every trial point per iteration.  'auto' (default) = ``False`` since round 3 (it was lazy from 8192
+    trajectories per iteration on): a launch lasts as long as its slowest trajectory, so two launches per iteration cost
+    more than one (256 starts x 8 experiments: 1.23 s eager, 1.74 s lazy per 100 iterations) -- and the cost the
+    state-only kernel returns differs from the sensitivity kernel's by the integration tolerance (its steps are chosen by
+    the state's error alone), which is what lmder's ftol = 1.5e-8 test resolves: with lazy trial points NO start is ever
+    reported converged (costs and parameters are as good).  Pass ``lazy_jacobian=True`` together with looser
+    ``ftol`` / tighter ``rtol`` where the saved sensitivity integrations matter.
 
     With a handful of starts the chip is mostly empty: ``variant='small_batch'`` (an integrator override) lets the
     sensitivity kernel use its small-batch split while starts x experiments x chunks <= 2048.
@@ -115,7 +118,7 @@ def levenberg_marquardt_batch(project, thetas0, max_iter=60, lambda0=1e-2, lambd
     if algorithm != 'marquardt':
         raise ValueError("fit_batch: unknown algorithm %r ('marquardt', 'trust_region' or 'trust_region_torch')" % (algorithm,))
     if lazy_jacobian == 'auto':
-        lazy_jacobian = len(thetas0) * max(1, len(project._experiments)) >= 8192
+        lazy_jacobian = False        # (see levenberg_marquardt_batch: lazy is opt-in since round 3)
     if project.reference_compat and project.n_total_rows != project.n_project_residuals:
         raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
                          "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
@@ -245,7 +248,7 @@ def _trust_region_batch(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
                          "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
     if lazy_jacobian == 'auto':
-        lazy_jacobian = len(thetas0) * max(1, len(project._experiments)) >= 8192
+        lazy_jacobian = False        # (see levenberg_marquardt_batch: lazy is opt-in since round 3)
     lib = _lib.load_library()
     ctx = project._model.device_model.ctx
     th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
@@ -404,7 +407,7 @@ def _trust_region_fused(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         raise ValueError("fit_batch needs reference_compat=False when priors are set: the reference leaves the "
                          "prior rows of the Jacobian zero (SURVEY.md section 8a, quirk 4)")
     if lazy_jacobian == 'auto':
-        lazy_jacobian = len(thetas0) * max(1, len(project._experiments)) >= 8192
+        lazy_jacobian = False        # (see levenberg_marquardt_batch: lazy is opt-in since round 3)
     lib = _lib.load_library()
     ctx = project._model.device_model.ctx
     th, _ = project._theta_dev(np.asarray(thetas0, dtype=np.float64) if not hasattr(thetas0, 'device') else thetas0)
