@@ -475,7 +475,7 @@ def stiff_cpu_legs(gm5, Pn, t_np):
                      Jacobian -- over the FULL span on the reference's 1000-point grid (~35 s);
       analytic_dfun  the reference's use_jac path (model/ode_model.py:114-120) with the generated analytic Jacobian of the
                      augmented system as Dfun, over t in [0, 0.1]; its full-span timing is measured once per round
-                     (scripts/cpu_leg_stiff50.py -> profiles/r03/stiff50_cpu_full_span.json) and quoted from there."""
+                     (tests/tools/cpu_leg_stiff50.py -> profiles/r03/stiff50_cpu_full_span.json) and quoted from there."""
     from oracle import odeint_oracle as oo
     try:
         from threadpoolctl import threadpool_limits
@@ -511,7 +511,7 @@ def stiff_cpu_legs(gm5, Pn, t_np):
                       "(GeneratedModel.sens_model_jac, col_deriv layout: the reference's use_jac path), t in [0, %.2f]: "
                       "%.1f s, %d LSODA steps, %d Jacobian evaluations" % (grid[n_pts - 1], d2, int(inf2['nst'][-1]),
                                                                           int(inf2['nje'][-1]))}
-        # the whole span, measured once per round by scripts/cpu_leg_stiff50.py (minutes of one core: not part of a
+        # the whole span, measured once per round by tests/tools/cpu_leg_stiff50.py (minutes of one core: not part of a
         # default bench run) and committed under profiles/
         import json
         import os

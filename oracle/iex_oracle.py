@@ -103,7 +103,7 @@ def integrate(gm, p, t_out, rtol=3e-9, atol=3e-12, order=0, t0=0.0, y0=None, s0=
     """Returns (Y (len(t_out), n), S (len(t_out), n*k) or None, info) with info = dict(n_steps, n_reject, n_eval,
     n_euler, status); status as the kernel's: 0 ok, 1 max_steps, 3 step_underflow.
 
-    ``predictor`` (experiments only, scripts/dev_iex_predictor.py; the kernel has no such thing): callable
+    ``predictor`` (experiments only, tests/tools/dev_iex_predictor.py; the kernel has no such thing): callable
     (j, m, h, Hs, y_n, ya, default, previous_sequence_states) -> Newton's starting point of step m of sequence j, in place
     of ``default`` (the polynomial through the sequence's own last points)."""
     n, k = gm.n_vars, gm.n_sens

@@ -180,7 +180,7 @@ def implicit_adaptive_defaults(o, explicit):
     if str(o.get('method', '')).lower() in IMPLICIT_EXTRAP:
         # Extrapolated implicit Euler: the estimate is the difference of the order-K and order-(K-1) results of a step,
         # the order-K result is what continues; the GLOBAL error that accumulates was measured on the 35 stiff50 vectors
-        # the real reference was run on, against their tight solutions (scripts/dev_iex_wide.py, profiles/r03/
+        # the real reference was run on, against their tight solutions (tests/tools/dev_iex_wide.py, profiles/r03/
         # iex_wide_tolerances.txt; worst sensitivity entry over the vectors, in parity units of 1e-8 |ref| + 5e-9):
         #     rtol 3e-9 atol 3e-12: 2.21 (median 0.30)    3e-9 / 3e-13: 0.77    1e-9 / 1e-12: 0.56    1e-9 / 3e-13: 0.32
         # -- the reference's own LSODA is 1.45 off by the same measure.  Round 3 first took 3e-9 / 3e-12 from the three

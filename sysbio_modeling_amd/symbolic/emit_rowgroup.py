@@ -51,7 +51,7 @@ from __future__ import annotations
 REG_ELEMS = 15      # elements per lane up to which DOPRI45's stage vectors fit 256 registers (two waves per SIMD)
 AGPR_ELEMS = 26     # ... up to which they fit 512 together with the operands (one wave per SIMD, v_accvgpr traffic); beyond: scratch
 # DOP853 keeps twelve vectors of a lane's elements alive where DOPRI45 keeps seven: its split (layout RG2) is planned with
-# budgets scaled by 7/12.  Measured on cascade20, 4096 vectors (scripts/dev_dop853.py): 14 elements per lane (the DOPRI45
+# budgets scaled by 7/12.  Measured on cascade20, 4096 vectors (tests/tools/dev_dop853.py): 14 elements per lane (the DOPRI45
 # split) 512 registers + 1078 scratch instructions, ~60 ms per pass; 7 elements in two column chunks 262 registers, no
 # scratch, ~3 ms.
 REG_ELEMS_853 = 8

@@ -2,7 +2,7 @@
 a default bench.py run: measured once per round and committed (profiles/<round>/stiff50_cpu_full_span.json), from where
 bench.py quotes it.
 
-    python scripts/cpu_leg_stiff50.py profiles/r03/stiff50_cpu_full_span.json [vector]
+    python tests/tools/cpu_leg_stiff50.py profiles/r03/stiff50_cpu_full_span.json [vector]
 
   as_reference   the reference's default call: odeint(..., Dfun=None, rtol=atol=1e-10) on its 1000-point grid
                  (model/ode_model.py:122-123) -- LSODA differences and factors a dense 2550 x 2550 Jacobian;
@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main(out_path, vector=3):

@@ -2,7 +2,7 @@
 default tolerances -- pass time, steps, and the distance of both from a tight solution on a few vectors."""
 import os, sys, time, warnings
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.simplefilter('ignore')
 import torch
 from sysbio_modeling_amd import models_zoo

@@ -1,8 +1,8 @@
 """Developer check of SBM_IMPLICIT_EXTRAP on the stiff50 ensemble: golden parity + time per 4096 vectors.
-usage: python scripts/dev_iex.py [n_vectors] [orders] [rtols]"""
+usage: python tests/tools/dev_iex.py [n_vectors] [orders] [rtols]"""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from sysbio_modeling_amd import _lib, models_zoo
 from sysbio_modeling_amd.symbolic import zoo_model

@@ -1,10 +1,10 @@
 """CPU experiment on the scheme oracle (oracle/iex_oracle.py): Newton evaluations per implicit-Euler step of the extrapolated
 scheme with the kernel's predictor (polynomial through the sequence's own last points) and with a predictor that takes the
 first steps of sequence j from the PREVIOUS sequence of the same macro step:  yb = ya + q(tau) - q(tau - h),  q = the
-quadratic (linear for j = 2) through the nearest states of sequence j - 1.  usage: python scripts/dev_iex_predictor.py [t_end]"""
+quadratic (linear for j = 2) through the nearest states of sequence j - 1.  usage: python tests/tools/dev_iex_predictor.py [t_end]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import iex_oracle
 from sysbio_modeling_amd.symbolic import zoo_model
 from sysbio_modeling_amd import models_zoo

@@ -1,8 +1,8 @@
 """Default tolerances of SBM_IMPLICIT_EXTRAP against the 35 real-reference stiff50 vectors (and their tight solutions):
-worst error over the vectors and time of the 4096-vector launch, per (rtol, atol).  usage: python scripts/dev_iex_wide.py"""
+worst error over the vectors and time of the 4096-vector launch, per (rtol, atol).  usage: python tests/tools/dev_iex_wide.py"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from sysbio_modeling_amd import _lib, models_zoo
 from sysbio_modeling_amd.symbolic import zoo_model
