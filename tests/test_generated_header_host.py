@@ -11,7 +11,9 @@ row -- patterns the zoo models do not have -- and general ones with feedback):
     without one;
   * ``im_solve_tri`` with the factors ``im_build`` / ``im_factor`` produce solves (I - gamma J_y) x = b (numpy);
   * ``im_solve_tri_pick`` hands lane i component i of the same solution;
-  * the symbolic LU of a NON-triangular J_y (fill-in worked out at generation time) solves its Newton matrix.
+  * the symbolic LU of a NON-triangular J_y (fill-in worked out at generation time) solves its Newton matrix;
+  * the row-DISTRIBUTED LU of densely coupled networks (lane-level code with SBM_LANE_BCAST), emulated one lane at a time,
+    solves it too.
 
 The GPU tests exercise these members inside the kernels on the zoo's patterns (tests/test_gpu_implicit.py)."""
 import ctypes
@@ -29,7 +31,18 @@ HARNESS = r'''
 #define SBM_RCP(x) (1.0 / (x))
 #define SBM_SEL(c, a, b) ((c) ? (a) : (b))
 #define SBM_PICK(scol, c, v, otherwise) ((scol) == (c) ? (v) : (otherwise))
-#define SBM_LANE_BCAST(v, src) (v)
+#include <vector>
+// SBM_LANE_BCAST(v, src) = the value of v in lane src.  One lane at a time on the host: the j-th broadcast of a (straight-line)
+// function is learnt by running the source lane up to it -- it depends on earlier broadcasts only -- and replayed to the others.
+struct Probe { int src; double v; };
+static std::vector<double> g_bc;
+static size_t g_idx;
+static inline double lane_bcast(double v, int src) {
+  const size_t j = g_idx++;
+  if (j < g_bc.size()) return g_bc[j];
+  throw Probe{src, v};
+}
+#define SBM_LANE_BCAST(v, src) lane_bcast((v), (src))
 #define SBM_LDS_FENCE()
 using std::fma;
 #include "%(header)s"
@@ -93,6 +106,37 @@ void eval_row(int row, double t, const double* y, const double* p, double* f, do
   for (int s = 0; s < M::RL_MAXJY; ++s) jy[s] = jyo[s];
   for (int s = 0; s < M::RL_MAXJP; ++s) jp[s] = jpo[s];
 }
+// the row-distributed factorisation (lane i owns row i of M) in lockstep emulation, then im_solve_lds on the published rows;
+// returns the number of broadcasts, -1 on an inconsistency
+int dist_factor_solve(const double* Md, double* b_io) {
+  constexpr int N = M::NV;
+  g_bc.clear();
+  double rd[N], row[N];
+  auto run = [&](int lane) {
+    for (int j = 0; j < N; ++j) row[j] = Md[lane * N + j];
+    g_idx = 0;
+    double (&m)[N] = row;
+    M::im_factor_rows(m, lane, rd);
+  };
+  for (;;) {
+    try { run(0); break; }
+    catch (const Probe& p) {
+      try { run(p.src); return -1; }
+      catch (const Probe& q) { g_bc.push_back(q.v); }
+    }
+  }
+  std::vector<double> mf((size_t)N * M::IM_LD + 2, 0.0);
+  for (int lane = 0; lane < N; ++lane) {
+    run(lane);
+    for (int j = 0; j < N; ++j) mf[(size_t)lane * M::IM_LD + j] = row[j];
+  }
+  double b[N];
+  for (int i = 0; i < N; ++i) b[i] = b_io[i];
+  M::im_solve_lds(mf.data(), rd, b);
+  for (int i = 0; i < N; ++i) b_io[i] = b[i];
+  return (int)g_bc.size();
+}
+int is_dist() { return M::IM_DIST ? 1 : 0; }
 void build_factor_solve(double gamma, const double* jy, double* b_io) {
   double m[M::IM_NM], b[M::NV];
   M::im_build(gamma, jy, m);
@@ -154,6 +198,7 @@ def _host_library(gm, tmp_path):
     lib.solve_tri.argtypes = [dp, dp]
     lib.solve_tri_pick.argtypes = [dp, dp, ctypes.c_int, dp]
     lib.build_factor_solve.argtypes = [ctypes.c_double, dp, dp]
+    lib.dist_factor_solve.argtypes = [dp, dp]
     lib.eval_row.argtypes = [ctypes.c_int, ctypes.c_double, dp, dp, dp, dp, dp]
     for f in ('jpcol', 'mfpos', 'jycol'):
         getattr(lib, f).argtypes = [ctypes.c_int, ctypes.c_int]
@@ -356,3 +401,35 @@ def test_fused_sensitivity_step_with_a_row_wider_than_a_block(tmp_path):
         lib.two_pass(_p(mf), _p(ja), 0.11, col, _p(a))
         lib.fused(_p(mf), _p(ja), 0.11, col, _p(b))
         assert np.array_equal(a, b), col
+
+
+@pytest.mark.parametrize('n,density', [(12, 1.0), (20, 0.5)])
+def test_row_distributed_lu_in_lockstep_emulation(tmp_path, n, density):
+    """Densely coupled networks get the row-DISTRIBUTED factorisation (emit_implicit.py::emit_distributed: lane i eliminates
+    in row i, pivot rows travel by SBM_LANE_BCAST, the rows are published to an LDS table that im_solve_lds reads).  Lane-level
+    code, run here one lane at a time with the broadcasts learnt from their source lanes (harness above): the factors of
+    (I - gamma J_y) for a random dense J_y solve the system numpy solves; the redundant form (im_factor / im_solve, every
+    lane the whole matrix) gives the same solution."""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    gm = GeneratedModel(models_zoo.dense_spec(n, density, name='dense%d_host%d' % (n, int(100 * density))))
+    lib = _host_library(gm, tmp_path)
+    assert lib.is_dist() == 1 and lib.is_tri() == 0
+    d = gm.derived
+    rng = np.random.default_rng(n)
+    jy = rng.standard_normal(lib.njy())
+    J = np.zeros((n, n))
+    for i in range(n):
+        for e, c in d.jy_rows[i]:
+            J[i, c] = jy[e]
+    gamma = 0.07
+    Mx = np.eye(n) - gamma * J
+    b0 = rng.standard_normal(n)
+    x = b0.copy()
+    n_bc = lib.dist_factor_solve(_p(np.ascontiguousarray(Mx)), _p(x))
+    assert n_bc > n                                              # pivots + the pivot rows' entries
+    x_ref = np.linalg.solve(Mx, b0)
+    assert np.allclose(x, x_ref, rtol=1e-11, atol=1e-13)
+    x2 = b0.copy()
+    lib.build_factor_solve(gamma, _p(np.concatenate([jy, [0.0, 0.0]])), _p(x2))
+    assert np.allclose(x2, x, rtol=1e-12, atol=1e-14)
