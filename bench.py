@@ -81,7 +81,7 @@ def build_workload(model, gm, n_vectors, rank):
 # CPU legs: the oracle (SciPy odeint restatement of the reference, compiled C RHS standing in for its numba)
 # timed on the GPU box's host cores over BOUNDED samples of the same workloads
 # ---------------------------------------------------------------------------
-def cpu_baseline(gm, theta_rows, budget_s=12.0, max_vectors=4096, sens=True, t_end=100.0):
+def cpu_baseline(gm, theta_rows, budget_s=8.0, max_vectors=4096, sens=True, t_end=100.0):
     """One host core; the reference's exact odeint call per vector on its 1000-point grid."""
     from oracle import odeint_oracle as oo
     grid = np.linspace(0, t_end, 1000)
@@ -114,31 +114,16 @@ def project_oracle_of(gm, proj):
 
 def residual_parity(gm, proj, theta_rows, res_gpu, jac_gpu, picks):
     """BASELINE.json's second figure: residual (and Jacobian) error of the timed GPU pass against the SciPy
-    restatement of the reference's Project on the same inputs, for ``picks`` (indices spread over the batch).
+    restatement of the reference's Project on the same inputs, for ``picks`` (indices spread over the batch), AND the
+    arbitration of that difference: the same rows from a tight integration, with the GPU's and SciPy's distance to it.
     Tolerance (oracle/tolerances.py): the sampled trajectories agree with the reference's LSODA to
     |gpu - ref| <= 1e-8 |ref| + 5e-9 (the absolute term is LSODA's own noise at atol = 1e-10); residual and
-    Jacobian rows get the first-order propagation of exactly that through the reference's formulas."""
-    from oracle import tolerances as tol
-    po = project_oracle_of(gm, proj)
-    a = proj.descriptor_arrays()
-    worst_r = worst_rel = worst_j = worst_n = 0.0
-    for v in picks:
-        rr, sims, B = po.residuals(theta_rows[v], return_parts=True)
-        Jm = po.model_jacobian(theta_rows[v])
-        Jr = po.calc_project_jacobian(theta_rows[v])
-        tau_s, tau_Jm = tol.lsoda_taus(a, theta_rows[v], sims, Jm)
-        t = tol.project_tolerances(a, sims, B, tau_s, Jm, tau_Jm)
-        worst_r = max(worst_r, tol.tol_ratio(res_gpu[v], rr, t['residuals']))
-        worst_rel = max(worst_rel, float(np.linalg.norm(res_gpu[v] - rr) / np.linalg.norm(rr)))
-        worst_j = max(worst_j, tol.tol_ratio(jac_gpu[v], Jr, t['jacobian']))
-        worst_n = max(worst_n, abs(float(np.sum(res_gpu[v] ** 2)) / float(np.sum(rr ** 2)) - 1.0))
-    return {"vectors_checked": len(picks), "residual_err_in_tolerance_units": worst_r,
-            "residual_rel_err": worst_rel, "jacobian_err_in_tolerance_units": worst_j,
-            "norm_rel_err": worst_n,
-            "tolerance": "trajectories |gpu - scipy| <= 1e-8 |scipy| + 5e-9 (LSODA's own absolute noise at atol "
-                         "1e-10), propagated to first order through B, (B s - d) / sigma and B J + s dB/dtheta "
-                         "(oracle/tolerances.py::project_tolerances); <= 1 passes",
-            "reference": "ProjectOracle: scipy.integrate.odeint rtol=atol=1e-10, reference_compat Jacobian"}
+    Jacobian rows get the first-order propagation of exactly that through the reference's formulas.  The oracle runs
+    are spread over the host cores (bench_configs.oracle_parity_pool)."""
+    import bench_configs as bc
+    out = bc.oracle_parity_pool(proj, proj.descriptor_arrays(), theta_rows, res_gpu, jac_gpu, picks, tight=True)
+    out["reference"] = "ProjectOracle: scipy.integrate.odeint rtol=atol=1e-10, reference_compat Jacobian"
+    return out
 
 
 def _cpu_worker(rows_budget):
@@ -159,7 +144,7 @@ def _cpu_worker(rows_budget):
     return steps, n, time.perf_counter() - t0
 
 
-def cpu_baseline_all_cores(theta_rows, budget_s=10.0):
+def cpu_baseline_all_cores(theta_rows, budget_s=6.0):
     """The same oracle on every host core the process may use: one worker
     process per core, each timing its own share.  Runs BEFORE this process touches the GPU (the workers
     are spawned, not forked)."""
@@ -317,6 +302,7 @@ def valu_roofline(key, k_ms, k_steps):
 
 
 _REAL_STDOUT = None
+T_START = time.perf_counter()
 
 
 def protect_stdout():
@@ -332,13 +318,162 @@ def protect_stdout():
         os.close(null)
 
 
+def _write_all(fd, data):
+    """os.write may write less than it was given (a pipe that is full): loop until the buffer is out."""
+    view = memoryview(data)
+    while len(view):
+        n = os.write(fd, view)
+        view = view[n:]
+
+
 def emit(obj):
-    line = (json.dumps(obj) + "\n").encode()
+    line = (json.dumps(obj, separators=(',', ':')) + "\n").encode()
     if _REAL_STDOUT is None:
-        sys.stdout.write(line.decode())
         sys.stdout.flush()
+        _write_all(1, line)
     else:
-        os.write(_REAL_STDOUT, line)
+        _write_all(_REAL_STDOUT, line)
+
+
+LINE_LIMIT = 4096          # the driver keeps an 8 KB tail of stdout: the headline line stays well inside it
+FULL_OUT = os.path.join(REPO, 'gpurun_out', 'bench_full.json')
+
+
+def _sig(x, digits=6):
+    """numbers at six significant digits, everything else unchanged (the full record keeps full precision)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float('%.*g' % (digits, x)) if np.isfinite(x) else None
+    if isinstance(x, (int, str)):
+        return x
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _compact_roofline(r, rv=None):
+    """{bound, achieved, peak, unit, frac, traffic, kernel, kernel_ms, achieved_fp64{...}} (+ valu_issue{...}): numbers only."""
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'kernel_ms'))
+    out['traffic'] = r.get('traffic')
+    if isinstance(r.get('achieved_fp64'), dict):
+        out['achieved_fp64'] = _pick(r['achieved_fp64'], ('achieved', 'peak', 'unit', 'frac'))
+    if isinstance(rv, dict):
+        out['valu_issue'] = _pick(rv, ('achieved', 'peak', 'unit', 'frac', 'valu_busy_fraction_pmc'))
+    return out
+
+
+def _compact_side(name, c):
+    """one side workload in a few numbers: time, rate, the fraction of the bound that applies, parity of the timed pass"""
+    if not isinstance(c, dict):
+        return None
+    if 'error' in c:
+        return {"error": str(c['error'])[:80]}
+    out = _pick(c, ('ms', 'value', 'seconds', 'fits_per_s', 'converged', 'starts', 'cost_median', 'failed_vectors',
+                    'n_gpus', 'scaling', 'macro_steps_per_vector', 'speedup_vs_one_core'))
+    r = c.get('roofline') or (c.get('dopri45') or {}).get('roofline')
+    if name == 'configs1' and isinstance(c.get('dopri45'), dict):
+        out.update(_pick(c['dopri45'], ('ms', 'value', 'failed_vectors')))
+    rv = c.get('roofline_valu_issue') or (c.get('dopri45') or {}).get('roofline_valu_issue')
+    if isinstance(r, dict):
+        # the bound that applies: VALU issue where the byte model says > 1 or the PMC figures exist, else the byte model
+        if isinstance(rv, dict):
+            out['roofline'] = {"bound": "valu_issue", "frac": rv.get('frac'), "valu_busy": rv.get('valu_busy_fraction_pmc'),
+                               "hbm_model_frac": r.get('frac')}
+        else:
+            out['roofline'] = {"bound": r.get('bound'), "frac": r.get('frac')}
+        if isinstance(r.get('achieved_fp64'), dict):
+            out['roofline']['fp64_frac'] = r['achieved_fp64'].get('frac')
+    par = c.get('parity_of_timed_pass') or (c.get('cpu_baseline') or {}).get('parity_of_timed_pass')
+    if isinstance(par, dict):
+        out['parity'] = {k: v for k, v in par.items() if isinstance(v, (int, float, bool)) and not k.startswith('oracle_')}
+    cb = c.get('cpu_baseline')
+    if isinstance(cb, dict):
+        out['cpu'] = _pick(cb, ('value', 'unit', 'cores', 'finished', 'seconds'))
+    if name == 'dense':
+        out = {k: {"valu_ms": v['valu']['ms'], "mfma_ms": v['mfma']['ms']} for k, v in c.items()
+               if isinstance(v, dict) and 'valu' in v and 'mfma' in v}
+    return out
+
+
+def compact_line(full, full_path=None):
+    """The LAST stdout line of bench.py: the contract's keys + `roofline` + `cpu_baseline`, numbers and short labels
+    only, at most LINE_LIMIT bytes.  Everything else (side configurations in full, kernel variants, formulas, notes)
+    is in the side file `full_path`.  Sheds the optional parts (smallest value first) if a line would still be too long."""
+    cfg = full.get('config', {})
+    line = {k: full.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+                                     'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
+    line['config'] = dict(_pick(cfg, ('vectors_per_gpu', 'n_equations', 'integrator', 'rtol', 'atol',
+                                      'accepted_steps_per_pass', 'failed_vectors')),
+                          workload=str(cfg.get('workload_short') or cfg.get('workload', ''))[:200])
+    line['roofline'] = _compact_roofline(full.get('roofline'), full.get('roofline_valu_issue'))
+    cb = full.get('cpu_baseline')
+    if isinstance(cb, dict):
+        c = _pick(cb, ('value', 'unit', 'cores', 'kind'))
+        c['sample'] = str(cb.get('sample_short') or cb.get('sample', ''))[:160]
+        if isinstance(full.get('cpu_baseline_all_cores'), dict):
+            c['all_cores'] = _pick(full['cpu_baseline_all_cores'], ('value', 'cores'))
+        if isinstance(cb.get('parity_of_timed_pass'), dict):
+            c['parity_of_timed_pass'] = {k: v for k, v in cb['parity_of_timed_pass'].items()
+                                         if isinstance(v, (int, float, bool)) and not k.startswith('oracle_')}
+        line['cpu_baseline'] = c
+    else:
+        line['cpu_baseline'] = None
+    rk = full.get('ranks')
+    if isinstance(rk, dict):
+        line['ranks'] = _pick(rk, ('world_size_seen', 'backend', 'nccl_version', 'ms_per_step_by_rank',
+                                   'gathered_norms_match_local_block'))
+    if isinstance(full.get('host_inclusive'), dict):
+        line['host_inclusive'] = _pick(full['host_inclusive'], ('value_host_inclusive',
+                                                                'value_host_inclusive_with_jacobian_download'))
+    if isinstance(full.get('product_default'), dict):
+        line['product_default'] = _pick(full['product_default'], ('integrator', 'ms_per_step'))
+    sides = {}
+    for name, c in (full.get('configs') or {}).items():
+        if name == 'configs3_sharded' and full.get('n_gpus') == 1:
+            continue            # (at N = 1 that entry repeats configs3)
+        s = _compact_side(name, c)
+        if s:
+            sides[name] = s
+    if sides:
+        line['configs'] = sides
+    line['full'] = full_path
+    line['build'] = full.get('build')
+    line = _sig(line)
+    # never longer than the limit: drop optional detail, least important first
+    for drop in (('configs', 'dense'), ('host_inclusive',), ('configs', 'fit'), ('configs', 'configs1'), ('build',),
+                 ('configs',), ('ranks', 'ms_per_step_by_rank'), ('product_default',)):
+        if len(json.dumps(line, separators=(',', ':'))) + 1 <= LINE_LIMIT:
+            break
+        d = line
+        for k in drop[:-1]:
+            d = d.get(k) if isinstance(d, dict) else None
+        if isinstance(d, dict):
+            d.pop(drop[-1], None)
+    return line
+
+
+def write_full(full, path=None):
+    path = path or FULL_OUT
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + '.tmp.%d' % os.getpid()
+        with open(tmp, 'w') as fh:
+            json.dump(full, fh, indent=1)
+        os.replace(tmp, path)
+        return os.path.relpath(path, REPO)
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write %s (%s); the full record goes to stderr\n" % (path, e))
+        sys.stderr.write(json.dumps(full) + "\n")
+        return None
 
 
 def main():
@@ -355,8 +490,12 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help="headline only: no other configs, no variants")
     ap.add_argument('--only', default=None, help="run one workload's GPU part alone, --steps times (profiling aid; "
                     "headline, configs1, configs3, configs4, fit, dense, dop853); no JSON contract")
+    ap.add_argument('--full-out', default=None, help="where the full record goes (default gpurun_out/bench_full.json); "
+                    "stdout carries ONE compact line")
     ap.add_argument('--cpu-baseline-only', action='store_true', help="time the CPU oracle and exit (no GPU needed)")
     args = ap.parse_args()
+    global T_START
+    T_START = time.perf_counter()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         # started as plain `python bench.py --gpus N`: become the launcher.  This process never imports torch or
@@ -475,9 +614,18 @@ def main():
         world_seen = dist.get_world_size()
         backend = dist.get_backend()
         norms_ok = bool(torch.equal(gathered[rank * V:(rank + 1) * V], out['norms']))
+        try:
+            nccl_version = '.'.join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001
+            nccl_version = None
+        # the multi-GPU line is an RCCL line or no line at all: outside the one-GPU rehearsal a run that did not see
+        # N ranks over nccl (= RCCL), or whose gathered norms differ from the local block, fails with a non-zero exit
+        if not rehearsal and (backend != 'nccl' or world_seen != args.gpus or not norms_ok):
+            raise SystemExit("bench.py --gpus %d: backend %r, %d ranks seen, gathered norms match local block: %s -- "
+                             "refusing to print a multi-GPU line" % (args.gpus, backend, world_seen, norms_ok))
     else:
         total_steps_per_pass = float(steps_per_pass)
-        per_rank_ms, world_seen, backend, norms_ok = [1e3 * dt / args.steps], 1, None, True
+        per_rank_ms, world_seen, backend, norms_ok, nccl_version = [1e3 * dt / args.steps], 1, None, True, None
     value = total_steps_per_pass * args.steps / dt
     if args.only == 'headline':
         emit({"headline": {"ms_per_step": 1e3 * dt / args.steps, "value": value,
@@ -544,22 +692,18 @@ def main():
         "value": value, "unit": "ODE-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[2]: cascade20 (20 states, 40 params) with full forward sensitivities "
-                               "(820 coupled ODEs), %d parameter vectors per GPU, %s; step = theta->p gather + "
-                               "integration + fused residual/Jacobian assembly (64 rows x 40 params, 4 scale "
-                               "factors)%s" % (V, "DOPRI45 at OdeModel's default tolerances rtol=%g atol=%g (they meet "
-                                               "SURVEY 8(d) against a tight solution; round 1 timed rtol=1e-9 atol=1e-12, "
-                                               "half the steps per pass at the same steps/s: extras."
-                                               "sens_dopri45_auto), 16 output times" % (tol['rtol'], tol['atol'])
-                                               if args.method == 'dopri45' else
-                                               ("DOP853 at rtol=%g atol=%g, 16 output times" % (tol['rtol'], tol['atol'])
-                                                if args.method == 'dop853' else "RK4 fixed, %d steps" % args.rk4_steps),
-                                               " + RCCL all-gather of residual norms" if world > 1 else ""),
+        "config": {"workload": "configs[2]: cascade20 (20 states, 40 params) + full forward sensitivities = 820 ODEs, %d "
+                               "vectors/GPU, %s, 16 output times; gather + integrate + residual/Jacobian assembly"
+                               % (V, {"dopri45": "DOPRI45", "dop853": "DOP853", "rk4": "RK4 fixed %d steps" % args.rk4_steps}[args.method]),
+                   "description": "step = theta->p gather + integration at OdeModel's DEFAULT tolerances + fused sample / residual / "
+                                  "Jacobian assembly (64 rows x 40 params, 4 scale factors)%s"
+                                  % (" + RCCL all-gather of residual norms" if world > 1 else ""),
                    "vectors_per_gpu": V, "n_equations": N_AUG, "integrator": args.method,
+                   "rtol": tol.get('rtol'), "atol": tol.get('atol'),
                    "accepted_steps_per_pass": total_steps_per_pass, "failed_vectors": n_bad},
         "roofline": roofline,
-        "ranks": {"world_size_seen": world_seen, "backend": backend, "ms_per_step_by_rank": per_rank_ms,
-                  "gathered_norms_match_local_block": norms_ok},
+        "ranks": {"world_size_seen": world_seen, "backend": backend, "nccl_version": nccl_version,
+                  "ms_per_step_by_rank": per_rank_ms, "gathered_norms_match_local_block": norms_ok},
     }
     if roofline_valu:
         result["roofline_valu_issue"] = roofline_valu
@@ -602,7 +746,9 @@ def main():
             result["extras"] = {"error": repr(e)[:300]}
     if rank == 0:
         result["build"] = dict(_CURRENT_STAMPS)
-        emit(result)
+        result["wall_seconds"] = time.perf_counter() - T_START
+        path = write_full(result, args.full_out)
+        emit(compact_line(result, path))
     if world > 1:
         dist.barrier()   # rank 0 arrives late
         dist.destroy_process_group()
