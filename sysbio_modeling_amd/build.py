@@ -143,13 +143,10 @@ def build_plugin(name, header_path, force=False, extra_flags=()):
         name = name + '_' + hashlib.sha1(' '.join(env_flags).encode()).hexdigest()[:8]
         extra_flags = tuple(extra_flags) + env_flags
     out = plugin_path(name)
-    srcs = [header_path, os.path.join(CSRC_DIR, 'sbm_plugin_main.hip'),
-            os.path.join(CSRC_DIR, 'sbm_integrators.hpp'), os.path.join(CSRC_DIR, 'sbm_implicit_adaptive.hpp'),
-            os.path.join(CSRC_DIR, 'sbm_implicit_extrap.hpp'),
-            os.path.join(CSRC_DIR, 'sbm_implicit_stepper.hpp'),
-            os.path.join(CSRC_DIR, 'sbm_sens_mfma.hpp'),
-            os.path.join(CSRC_DIR, 'sbm_plugin.h'),
-            os.path.join(REPO_DIR, 'include', 'sbm.h')]
+    # every header of csrc/ goes into the stamp (round 4 added one and the explicit list missed it: stale plugins)
+    srcs = [header_path, os.path.join(CSRC_DIR, 'sbm_plugin_main.hip')] + \
+        sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(('.hpp', '.h'))) + \
+        [os.path.join(REPO_DIR, 'include', 'sbm.h')]
     def cmd_for(o):
         return [hipcc_path(), '--offload-arch=' + OFFLOAD_ARCH, '-O3', '-std=c++17', '-fPIC', '-shared',
                 '-DSBM_MODEL_HEADER="%s"' % os.path.abspath(header_path), *extra_flags,

@@ -62,6 +62,14 @@ __device__ __forceinline__ double sbm_pick(int scol, int c, double v, double oth
 #define SBM_PICK(scol, c, v, otherwise) sbm_pick(scol, c, v, otherwise)
 __device__ __forceinline__ double sbm_sel(bool c, double a, double b) { return c ? a : b; }
 #define SBM_SEL(c, a, b) sbm_sel(c, a, b)
+// (col == c ? v : otherwise) for col = lane + 64 * chunk (chunk wave-uniform) and a literal c: the lane mask comes from
+// scalar instructions (the inverse of a ballot: s_mov / s_cselect of the literal), the select is the v_cndmask pair alone
+__device__ __forceinline__ double sbm_pick_col(int col, int c, double v, double otherwise) {
+  const int chunk = __builtin_amdgcn_readfirstlane(col) >> 6;       // lane 0 holds 64 * chunk
+  const unsigned long long mask = (c >> 6) == chunk ? (1ull << (c & 63)) : 0ull;
+  return __builtin_amdgcn_inverse_ballot_w64(mask) ? v : otherwise;
+}
+#define SBM_PICK_COL(col, c, v, otherwise) sbm_pick_col(col, c, v, otherwise)
 // value of `v` in lane `src` (compile-time constant) as a wave-uniform scalar: two v_readlane_b32
 __device__ __forceinline__ double sbm_lane_bcast(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -1953,6 +1961,7 @@ __global__ void __launch_bounds__(64) sbm_imid_kernel(sbm_kernel_args a) {
 
 #include "sbm_implicit_adaptive.hpp"
 #include "sbm_implicit_extrap.hpp"
+#include "sbm_implicit_extrap_seq.hpp"
 #include "sbm_sens_mfma.hpp"
 
 // What the implicit kernels can hold: every lane keeps a whole column of S (NV values) and the solver's work vector
@@ -1970,6 +1979,71 @@ struct SbmImplicitFits {
 template <class T>
 struct SbmTypeTag { using type = T; };
 
+// ---- scratch of the persistent kernels: one buffer per (device, stream), grown on demand, never shrunk.  Launches on
+// one stream run one after the other, so they can share it; two contexts on two streams get one each. ----
+#include <map>
+#include <mutex>
+#include <utility>
+#include <stdlib.h>
+#include <stdio.h>
+struct SbmScratch {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int* counter = nullptr;      // the work counter of a persistent launch (zeroed on the stream before every launch)
+};
+static hipError_t sbm_scratch_for(hipStream_t stream, size_t need, SbmScratch** out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, SbmScratch> table;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  SbmScratch& s = table[std::make_pair(dev, (void*)stream)];
+  if (!s.counter) {
+    e = hipMalloc((void**)&s.counter, 256);
+    if (e != hipSuccess) { s.counter = nullptr; return e; }
+  }
+  if (s.bytes < need) {
+    // work enqueued earlier on this stream may still read the old buffer
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    if (s.p) (void)hipFree(s.p);
+    s.p = nullptr;
+    s.bytes = 0;
+    e = hipMalloc(&s.p, need);
+    if (e != hipSuccess) { s.p = nullptr; return e; }
+    s.bytes = need;
+  }
+  *out = &s;
+  return hipSuccess;
+}
+// how many workgroups of `kernel` the device holds at once (cached per kernel and device)
+static hipError_t sbm_resident_blocks(const void* kernel, int block, int* out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> cache;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(std::make_pair(dev, kernel));
+  if (it == cache.end()) {
+    int per_cu = 0, cus = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    it = cache.emplace(std::make_pair(dev, kernel), per_cu * cus).first;
+  }
+  *out = it->second;
+  return hipSuccess;
+}
+// developer A/B switch: SBM_IEX_SEQ=0 runs chain models through sbm_iex_kernel as round 3 did
+static bool sbm_iex_seq_enabled() {
+  static const bool on = [] { const char* v = getenv("SBM_IEX_SEQ"); return !(v && v[0] == '0'); }();
+  return on;
+}
+
 template <class M>
 static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t stream) {
   const sbm_kernel_args a = *args;
@@ -1983,6 +2057,33 @@ static int sbm_launch_model(int kind, const sbm_kernel_args* args, hipStream_t s
         if (e == hipSuccess && a.n_steps) e = hipMemsetAsync(a.n_steps, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
         if (e == hipSuccess && a.n_reject) e = hipMemsetAsync(a.n_reject, 0, sizeof(int32_t) * (size_t)a.n_traj, stream);
         if (e != hipSuccess) return (int)e;
+      }
+      if constexpr (SbmIexSeqFits<M>::value) {
+        // chain models, order <= 8: sequences side by side + persistent wavefronts (sbm_implicit_extrap_seq.hpp)
+        int K = a.opts.step_mult;
+        const double rtol = a.opts.rtol > 0.0 ? a.opts.rtol : 1e-8;
+        if (K <= 0) K = rtol >= 1e-4 ? 4 : (rtol >= 1e-6 ? 6 : 8);
+        if (K <= SbmIexSeqPlan<M>::KMAX && sbm_iex_seq_enabled()) {
+          const int n_work = a.n_traj * nch;
+          int resident = 0;
+          // columns held rotated (chain + one J_p entry per column: no select in the column step) unless the caller hands
+          // in initial sensitivities, which need not respect the structure
+          constexpr bool kRot = SbmIexSeqPlan<M>::ROT_OK;
+          const bool rot = kRot && a.s0 == nullptr;
+          const void* kfn = rot ? (const void*)sbm_iex_seq_kernel<M, kRot> : (const void*)sbm_iex_seq_kernel<M, false>;
+          hipError_t e = sbm_resident_blocks(kfn, 64, &resident);
+          if (e != hipSuccess) return (int)e;
+          const int grid = n_work < resident ? n_work : resident;
+          if (getenv("SBM_DEBUG_LAUNCH")) fprintf(stderr, "sbm_iex_seq_kernel: %d pieces of work, %d resident workgroups, grid %d\n", n_work, resident, grid);
+          SbmScratch* sc = nullptr;
+          e = sbm_scratch_for(stream, (size_t)grid * SbmIexSeqPlan<M>::BLOCK_DOUBLES * sizeof(double), &sc);
+          if (e != hipSuccess) return (int)e;
+          e = hipMemsetAsync(sc->counter, 0, sizeof(int), stream);
+          if (e != hipSuccess) return (int)e;
+          if (rot) hipLaunchKernelGGL((sbm_iex_seq_kernel<M, kRot>), dim3(grid), dim3(64), 0, stream, a, (double*)sc->p, sc->counter, n_work, nch);
+          else hipLaunchKernelGGL((sbm_iex_seq_kernel<M, false>), dim3(grid), dim3(64), 0, stream, a, (double*)sc->p, sc->counter, n_work, nch);
+          return (int)hipGetLastError();
+        }
       }
       hipLaunchKernelGGL((sbm_iex_kernel<M>), dim3(a.n_traj, nch), dim3(64), 0, stream, a);
       return (int)hipGetLastError();

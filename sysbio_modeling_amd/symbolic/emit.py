@@ -71,6 +71,11 @@ def _canon_rcp(expr):
 
     def repl(e):
         if e.exp.is_Integer:
+            # denominators that differ by a rational factor share one reciprocal: 1 / (y + 1/2) = 2 / (2 y + 1)
+            # (stiff50's activation law produces both; a v_rcp_f64 with its two Newton steps is ~35 cycles)
+            content, prim = e.base.as_content_primitive()
+            if content != 1 and content.is_Rational and content > 0:
+                return sympy.Pow(content, e.exp) * sympy.Pow(_RCP(prim), -e.exp)
             return sympy.Pow(_RCP(e.base), -e.exp)
         return _RCP(sympy.Pow(e.base, -e.exp))
     return expr.replace(is_neg_pow, repl)

@@ -243,24 +243,30 @@ def emit_members(spec, d):
                     % (len(rows_b), b, rows_b[0])]
 
         def pick(b, i):
-            # (tried: the pick as ONE v_fmac under a one-lane EXEC set from literals by scalar instructions, 3 instead of
-            # 6 vector instructions per row -- 105 ms against 106 for configs[4]: the vector pipe is not what this kernel
-            # waits for at one wavefront per SIMD; not kept)
+            # The pick of J_p[i][column of this lane]: SBM_PICK_COL -- a v_cndmask pair under a lane mask that SCALAR
+            # instructions make from the literal column index (s_mov / s_cselect: inverse ballot), where `col == c`
+            # costs a vector compare per non-zero on top (round 4: 50 of 300 vector instructions per step of stiff50).
+            # (tried in round 3: the pick as ONE v_fmac under a one-lane EXEC set from literals by scalar instructions
+            # -- no gain: every EXEC write stalls the vector instruction behind it)
             rows_b = blocks[b]
             expr = "0.0"
             for q, (_, c) in reversed(list(enumerate(d.jp_rows[i]))):
-                expr = "SBM_SEL(col == %d, a%d[%d * RL_MAXJP + %d], %s)" % (c, b, i - rows_b[0], q, expr)
+                expr = "SBM_PICK_COL(col, %d, a%d[%d * RL_MAXJP + %d], %s)" % (c, b, i - rows_b[0], q, expr)
             return ["    z[%d] = fma(hh, %s, z[%d]);" % (i, expr, i)] if d.jp_rows[i] else []
         L += ["  // z <- M^-1 (z + hh * J_p[:, column of this lane]) with the J_p table `ja` ([row][RL_MAXJP], columns rl_jpcol), the",
               "  // factors `mf`; col = the sensitivity column of this lane",
               "  static constexpr bool IM_SENS_TRI = true;",
               "  static constexpr int IM_JP = RL_MAXJP > 0 ? RL_MAXJP : 1;",
               "  __device__ __forceinline__ static void im_sens_tri(const double* mf, const double* ja, double hh, int col, double (&z)[NV]) {\n    (void)col;"]
+        # (two blocks ahead: one block of four rows is ~100 cycles of arithmetic, a ds_read_b128 comes back after ~130 --
+        # one block ahead left a quarter of every block waiting at one wavefront per SIMD)
         L += loads(0)
+        if len(blocks) > 1:
+            L += loads(1)
         for b, rows_b in enumerate(blocks):
             L.append("    SBM_LDS_FENCE();")
-            if b + 1 < len(blocks):
-                L += loads(b + 1)
+            if b + 2 < len(blocks):
+                L += loads(b + 2)
             base = rstart[rows_b[0]]
             for i in rows_b:
                 L += pick(b, i)
@@ -275,15 +281,34 @@ def emit_members(spec, d):
         # recurrence x_i = b_i + a_i x_{i-1} over the row lanes -- a parallel prefix (sbm_implicit_stepper.hpp)
         chain = n <= 64 and all(c == r or c == r - 1 for (r, c) in pattern)
         L += ["  static constexpr bool IM_CHAIN = %s;" % ("true" if chain else "false")]
+        # A chain whose sensitivity columns each have ONE non-zero of J_p (a parameter enters one equation): column c of S
+        # is zero above that row r0(c) (a chain hands nothing upwards), so a lane may hold its column ROTATED -- register
+        # k = row (r0(c) + k) mod NV -- and the J_p term enters at k = 0 in every lane: the step of a column is
+        # z_k = rd[r0 + k] z_k + cc[r0 + k] z_{k-1} with per-lane table addresses and no select at all
+        # (sbm_implicit_extrap_seq.hpp).  IM_R0 / IM_JPQ: row and J_p slot of the column's entry.
+        col_entries = {}
+        for i in range(n):
+            for q, (_, c) in enumerate(d.jp_rows[i]):
+                col_entries.setdefault(c, []).append((i, q))
+        n_cols = (max(col_entries) + 1) if col_entries else 0
+        rot = chain and n_cols > 0 and all(len(col_entries.get(c, [])) == 1 for c in range(n_cols))
+        L += ["  static constexpr bool IM_ROT = %s;" % ("true" if rot else "false"),
+              "  __device__ __forceinline__ static int im_r0(int col) { return SBM_IM_R0[IM_ROT ? col : 0]; }",
+              "  __device__ __forceinline__ static int im_jpq(int col) { return SBM_IM_JPQ[IM_ROT ? col : 0]; }"]
         L += emit_distributed(spec, d, pattern, ops)
-        return L, dict(tri=True, rstart=rstart, pos=pos, nm=n_table)
+        return L, dict(tri=True, rstart=rstart, pos=pos, nm=n_table, rot=rot,
+                       r0=[col_entries[c][0][0] for c in range(n_cols)] if rot else [0],
+                       jpq=[col_entries[c][0][1] for c in range(n_cols)] if rot else [0])
     L += ["  __device__ __forceinline__ static void im_solve_tri(const double*, double (&)[NV]) {}",
           "  template <int RPL>",
           "  __device__ __forceinline__ static void im_solve_tri_pick(const double*, const double*, int, double (&)[RPL]) {}",
           "  static constexpr bool IM_SENS_TRI = false;",
           "  __device__ __forceinline__ static void im_sens_tri(const double*, const double*, double, int, double (&)[NV]) {}",
           "  static constexpr int IM_MF = IM_NM;",
-          "  static constexpr bool IM_CHAIN = false;"]
+          "  static constexpr bool IM_CHAIN = false;",
+          "  static constexpr bool IM_ROT = false;",
+          "  __device__ __forceinline__ static int im_r0(int) { return 0; }",
+          "  __device__ __forceinline__ static int im_jpq(int) { return 0; }"]
     L += emit_distributed(spec, d, pattern, ops)
     return L, dict(tri=False, nm=nm)
 
@@ -296,7 +321,8 @@ def emit_tables(spec, d, meta):
     max_jy = max([len(x) for x in d.jy_rows] + [1])
     if not meta['tri']:
         return ["__constant__ short SBM_IM_RSTART[1] = {0};", "__constant__ short SBM_IM_DIAGSLOT[1] = {-1};",
-                "__constant__ short SBM_IM_MFPOS[1] = {0};", ""]
+                "__constant__ short SBM_IM_MFPOS[1] = {0};", "__constant__ short SBM_IM_R0[1] = {0};",
+                "__constant__ short SBM_IM_JPQ[1] = {0};", ""]
     nm = meta['nm']
     diag = [-1] * n
     mfpos = [[nm] * n for _ in range(max_jy)]
@@ -310,4 +336,6 @@ def emit_tables(spec, d, meta):
             "__constant__ short SBM_IM_RSTART[%d] = {%s};" % (n, ", ".join(str(v) for v in meta['rstart'])),
             "__constant__ short SBM_IM_DIAGSLOT[%d] = {%s};" % (n, ", ".join(str(v) for v in diag)),
             "__constant__ short SBM_IM_MFPOS[%d] = {%s};" % (max_jy * n, ", ".join(str(v) for sl in mfpos for v in sl)),
+            "__constant__ short SBM_IM_R0[%d] = {%s};" % (len(meta['r0']), ", ".join(str(v) for v in meta['r0'])),
+            "__constant__ short SBM_IM_JPQ[%d] = {%s};" % (len(meta['jpq']), ", ".join(str(v) for v in meta['jpq'])),
             ""]

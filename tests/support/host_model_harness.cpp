@@ -16,6 +16,7 @@
 #define SBM_LDS_FENCE() ((void)0)
 #define SBM_PICK(scol, c, v, otherwise) ((scol) == (c) ? (v) : (otherwise))
 #define SBM_SEL(c, a, b) ((c) ? (a) : (b))
+#define SBM_PICK_COL(col, c, v, otherwise) ((col) == (c) ? (v) : (otherwise))
 // On the device SBM_LANE_BCAST(jy[slot], lane) reads register jy[slot] of another lane.  Here the
 // "lane registers" are the table g_lane_jy[lane][slot]; `v` names jy[slot] of an array whose base
 // address is g_bcast_base, which recovers the slot.

@@ -31,6 +31,7 @@ HARNESS = r'''
 #define SBM_RCP(x) (1.0 / (x))
 #define SBM_SEL(c, a, b) ((c) ? (a) : (b))
 #define SBM_PICK(scol, c, v, otherwise) ((scol) == (c) ? (v) : (otherwise))
+#define SBM_PICK_COL(col, c, v, otherwise) ((col) == (c) ? (v) : (otherwise))
 #include <vector>
 // SBM_LANE_BCAST(v, src) = the value of v in lane src.  One lane at a time on the host: the j-th broadcast of a (straight-line)
 // function is learnt by running the source lane up to it -- it depends on earlier broadcasts only -- and replayed to the others.
