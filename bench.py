@@ -398,6 +398,11 @@ def _compact_side(name, c):
     cb = c.get('cpu_baseline')
     if isinstance(cb, dict):
         out['cpu'] = _pick(cb, ('value', 'unit', 'cores', 'finished', 'seconds'))
+    if name == 'fit' and isinstance(c.get('with_priors'), dict) and 'error' not in c['with_priors']:
+        wp = c['with_priors']
+        out['with_priors'] = _pick(wp, ('seconds', 'fits_per_s', 'converged', 'starts', 'cost_median', 'speedup_vs_one_core'))
+        if isinstance(wp.get('cpu_baseline'), dict):
+            out['with_priors']['cpu'] = _pick(wp['cpu_baseline'], ('value', 'unit', 'cores', 'finished', 'seconds', 'costs_agree_to_1e-6'))
     if name == 'dense':
         out = {k: {"valu_ms": v['valu']['ms'], "mfma_ms": v['mfma']['ms']} for k, v in c.items()
                if isinstance(v, dict) and 'valu' in v and 'mfma' in v}

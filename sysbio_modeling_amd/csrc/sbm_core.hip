@@ -1079,8 +1079,11 @@ extern "C" int sbm_project_trajectory_steps(sbm_project* p, int32_t V, int32_t* 
   if (V < 0) return sbm_fail(SBM_E_ARG, "sbm_project_trajectory_steps: V < 0");
   const size_t T = (size_t)V * p->E;
   if (T == 0) return 0;
-  if (!p->traj_steps.p || p->traj_steps.n < T)
-    return sbm_fail(SBM_E_ARG, "sbm_project_trajectory_steps: the project has not evaluated %d vectors yet", V);
+  // the counts of the LAST evaluation, whatever the buffer could hold: a V other than that evaluation's would hand back
+  // stale or uninitialised counts with a success code (round 3 checked the capacity only)
+  if (!p->traj_steps.p || p->traj_steps.n < T || p->scratch_V != V)
+    return sbm_fail(SBM_E_ARG, "sbm_project_trajectory_steps: V = %d, but the project's last evaluation had %d vectors", V,
+                    p->traj_steps.p ? p->scratch_V : 0);
   SBM_HIP(hipSetDevice(p->model->ctx->device));
   SBM_HIP(hipMemcpyAsync(steps_dev, p->traj_steps.p, T * sizeof(int32_t), hipMemcpyDeviceToDevice, p->model->ctx->stream));
   return 0;

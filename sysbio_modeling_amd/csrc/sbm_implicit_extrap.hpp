@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(64) sbm_iex_kernel(sbm_kernel_args a) {
 #pragma unroll
           for (int i = 0; i < NV; ++i) {
             const double tk = sh.ZN[i * ZS + zl] + zh[i];
-            const float r = (float)ze[i] * __builtin_amdgcn_rcpf((float)fma(rtol, fmax(fabs(tk), floor_rel * colmax_new), atol));
+            // (the scale clamped in double: an atol below ~1e-38 must not turn into 1 / 0 in single precision)
+            const float r = (float)ze[i] * __builtin_amdgcn_rcpf((float)fmax(fma(rtol, fmax(fabs(tk), floor_rel * colmax_new), atol), 1e-30));
             cs = fmaf(r, r, cs);
           }
         }
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(64) sbm_iex_kernel(sbm_kernel_args a) {
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
           const double yk = yn[r] + yh[r];
-          const float ry = st.has_row[r] ? (float)ye[r] * __builtin_amdgcn_rcpf((float)fma(rtol, fmax(fabs(yk), floor_rel * (double)ykmax), atol)) : 0.f;
+          const float ry = st.has_row[r] ? (float)ye[r] * __builtin_amdgcn_rcpf((float)fmax(fma(rtol, fmax(fabs(yk), floor_rel * (double)ykmax), atol), 1e-30)) : 0.f;
           ry2 += sbm_nan_to_inf(ry * ry);
         }
         const float xs = sbm_wave_sumf(ry2);

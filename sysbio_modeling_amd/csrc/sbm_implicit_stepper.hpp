@@ -339,7 +339,7 @@ struct SbmImplicitStepper {
       for (int r = 0; r < RPL; ++r) {
         const double dd = has_row[r] ? d[r] : 0.0;
         yb[r] -= dd;
-        rmax = fmaxf(rmax, has_row[r] ? sbm_nan_to_inf((float)fabs(dd) * __builtin_amdgcn_rcpf((float)fma(nrtol, fabs(yb[r]), natol))) : 0.f);
+        rmax = fmaxf(rmax, has_row[r] ? sbm_nan_to_inf((float)fabs(dd) * __builtin_amdgcn_rcpf((float)fmax(fma(nrtol, fabs(yb[r]), natol), 1e-30))) : 0.f);
       }
       const float rr = sbm_wave_max(rmax);
       if (!(rr < 3.0e38f)) return SBM_NON_FINITE;

@@ -129,20 +129,31 @@ class Project(object):
     def _resolve_callback_mappings(self):
         """'custom' mappings given as the reference's callbacks: traced and compiled on first sight of an experiment
         that carries the measure (observables.trace_callback_observable)."""
-        from .observables import compile_observable, trace_callback_observable
+        from .observables import ObservableError, compile_observable, trace_callback_observable
+        import sympy
         for measure_name, m in self._measurement_to_model_map.items():
-            if m['type'] != 'custom' or m.get('program') is not None:
+            if m['type'] != 'custom' or not m.get('callbacks'):
                 continue
+            # The reference hands `experiment` and `measurement` to the callback on EVERY call (base_project.py:380-383): a
+            # callback may branch on them.  The kernel evaluates ONE program per measure, so the callback is traced on every
+            # experiment / measurement that carries the measure and the traces must agree; one that does not (a
+            # per-experiment weight, say) is refused rather than evaluated with the first experiment's formula.
+            first = None
             for experiment in self._experiments:
-                ms = [x for x in experiment.measurements if x.variable_name == measure_name]
-                if not ms:
-                    continue
-                par, fn, jac = m['callbacks']
-                expr = trace_callback_observable(par, fn, jac, m['names'], experiment, ms[0],
-                                                 len(experiment.param_global_vector_idx))
-                comp = compile_observable(expr, m['names'])
+                for meas in [x for x in experiment.measurements if x.variable_name == measure_name]:
+                    par, fn, jac = m['callbacks']
+                    expr = trace_callback_observable(par, fn, jac, m['names'], experiment, meas,
+                                                     len(experiment.param_global_vector_idx))
+                    if first is None:
+                        first = (expr, experiment.name)
+                    elif sympy.simplify(sympy.sympify(expr) - sympy.sympify(first[0])) != 0:
+                        raise ObservableError(
+                            "'custom' mapping of %s: the callback computes %s on experiment %s and %s on experiment %s; one "
+                            "compiled expression serves every experiment -- give the mapping as an expression, or one "
+                            "measure name per formula" % (measure_name, first[0], first[1], expr, experiment.name))
+            if first is not None:
+                comp = compile_observable(first[0], m['names'])
                 m['variables'], m['program'] = list(comp['variables']), comp
-                break
 
     def _update_project_settings(self):
         self._project_param_idx, self._n_project_params, self._residuals_per_param = self._set_local_param_idx()

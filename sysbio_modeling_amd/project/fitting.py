@@ -496,6 +496,7 @@ def _trust_region_fused(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         _lib.check(lib.sbm_lm_update(ctx.handle, p(cost), p(tr['norms']), p(tr['status']), p(pred), p(dxnorm), p(gtx), p(st),
                                      p(th), p(dscale), V, q, float(ftol), float(xtol), it, 1 if it == 0 else 0, p(radius),
                                      p(lam), p(done), p(accept), p(n_iter), p(counters), p(ratio)), 'sbm_lm_update')
+        veto_live = 0
         if lazy_jacobian:
             # MINPACK's economy: the state + sensitivity system only at the trial points that were accepted
             sel = torch.nonzero(accept).flatten()
@@ -504,7 +505,15 @@ def _trust_region_fused(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
                 integrate(trial[sel].contiguous(), opts_t, sub, True)
                 n_jac += int(sel.numel())
                 good = torch.isfinite(sub['norms']) & (sub['status'] == 0)
-                accept[sel[~good]] = 0
+                vetoed = sel[~good]
+                accept[vetoed] = 0
+                # sbm_lm_update ran BEFORE this re-integration: a start whose accepted step is vetoed here (the sensitivity
+                # system could not be integrated at the trial point) has not moved, so it has not converged on that step
+                # either -- it goes on from where it was
+                veto_live = int(vetoed.numel())
+                if veto_live:
+                    done[vetoed] = 0
+                    n_iter[vetoed] = int(max_iter)
                 tr['r'][sel] = sub['r']
                 tr['norms'][sel] = sub['norms']
                 if 'J' not in tr:
@@ -517,6 +526,8 @@ def _trust_region_fused(project, thetas0, max_iter=60, ftol=1.49012e-8, xtol=1.4
         _lib.check(lib.sbm_lm_accept(ctx.handle, p(accept), V, M, q, p(trial), p(tr['r']), p(tr['J']), p(tr['norms']), p(th),
                                      p(cur['r']), p(cur['J']), p(cost)), 'sbm_lm_accept')
         live, n_acc = (int(x) for x in counters.cpu())          # (the one read-back of the iteration)
+        if lazy_jacobian and veto_live:
+            live, n_acc = int((done == 0).sum()), n_acc - veto_live
         if trace:
             running = done == 0
             md = lambda t: float(t[running].median()) if bool(running.any()) else 0.0     # noqa: E731

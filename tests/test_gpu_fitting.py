@@ -374,3 +374,27 @@ def test_fit_and_sampler_on_a_model_with_its_own_context(gpu_models):
         assert np.array_equal(a, b)
     own.disable_jit()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_trajectory_steps_belong_to_the_last_evaluation(gpu_models):
+    """sbm_project_trajectory_steps hands out the per-trajectory step counts of the project's LAST evaluation: asking
+    with another V -- one that the scratch buffers of an earlier, larger batch could hold -- is an argument error, not a
+    success with stale counts (round 3 checked the capacity only; the fit's trial budget is derived from this call)."""
+    import torch
+    from sysbio_modeling_amd import _lib, models_zoo
+    model = gpu_models('cascade20')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        proj, th0 = models_zoo.cascade_config4_project(model, n_exp=2)
+    lib = _lib.load_library()
+    th = th0[None, :] + 0.05 * np.random.default_rng(3).standard_normal((12, th0.size))
+    proj.evaluate_batch(th, want=('n_steps',))
+    per = torch.empty((12, 2), dtype=torch.int32, device='cuda')
+    _lib.check(lib.sbm_project_trajectory_steps(proj._device(), 12, _lib.dev_ptr(per)), 'steps')
+    total = np.asarray(proj.evaluate_batch(th[:5], want=('n_steps',))['n_steps'])
+    per5 = torch.empty((5, 2), dtype=torch.int32, device='cuda')
+    _lib.check(lib.sbm_project_trajectory_steps(proj._device(), 5, _lib.dev_ptr(per5)), 'steps')
+    assert np.array_equal(per5.sum(dim=1).cpu().numpy(), total) and torch.equal(per5, per[:5])
+    with pytest.raises(_lib.SbmError, match="last evaluation had 5"):
+        _lib.check(lib.sbm_project_trajectory_steps(proj._device(), 12, _lib.dev_ptr(per)), 'steps')

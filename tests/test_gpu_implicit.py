@@ -724,3 +724,23 @@ def test_stiff_integrator_edge_cases(gpu_models, zoo):
         tol = 1.0 if K > 3 else 300.0
         assert parity_err(Yo[0], Yrr[[0, 400, 999]]) <= tol and parity_err(So[0], Srr[[0, 400, 999]]) <= tol, K
     assert steps[3] > steps[4] and steps[2] > steps[3], steps
+
+
+@pytest.mark.gpu
+def test_stiff_integrator_with_a_vanishing_atol(gpu_models):
+    """The controllers scale their errors in single precision: with atol below the smallest float (1e-40) the scale of a
+    component that is exactly zero -- every sensitivity at t0 -- used to become 1 / 0: every macro step was rejected and
+    the trajectory ended in SBM_STEP_UNDERFLOW after 200 000 attempts.  The scale is clamped in double precision: both
+    kernels (a chain model: sbm_iex_seq_kernel; another: sbm_iex_kernel) integrate, and agree with the run at an ordinary
+    atol within the tolerance."""
+    cases = (('simple', np.array([[0.001, 0.01], [0.01, 0.01]]), np.array([0.0, 10.0, 50.0, 100.0])),
+             ('michaelis_menten', np.stack([rc.MM_PARAMS * np.array([40.0, 30.0, 5.0, 3.0, 20.0])] * 2), np.array([0.0, 10.0, 50.0])))
+    for name, P, tt in cases:
+        m = gpu_models(name)
+        S0, Y0 = m.calc_jacobian_batch(P, tt, return_states=True, method='implicit_extrap', rtol=1e-7, atol=1e-13)
+        assert not m.last_info['status'].any()
+        S1, Y1 = m.calc_jacobian_batch(P, tt, return_states=True, method='implicit_extrap', rtol=1e-7, atol=1e-40)
+        assert not m.last_info['status'].any(), (name, m.last_info)
+        assert np.isfinite(S1).all() and np.isfinite(Y1).all()
+        assert np.max(np.abs(Y1 - Y0) / (1e-6 * np.abs(Y0) + 1e-12)) <= 1.0, name
+        assert np.max(np.abs(S1 - S0) / (1e-6 * np.maximum(np.abs(S0), 1e-6 * np.abs(S0).max()) + 1e-12)) <= 1.0, name

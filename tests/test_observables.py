@@ -226,3 +226,49 @@ def test_custom_observables_in_a_project_against_reference_style_callbacks(gpu_m
     out_cb = proj_cb.evaluate_batch(thetas, jacobian=True, want=('jacobian', 'model_jacobian', 'sf_gradient'))
     for key in ('sims', 'residuals', 'jacobian', 'model_jacobian'):
         assert np.array_equal(out_cb[key], out[key]), key
+
+
+def test_callback_that_depends_on_the_experiment_is_refused_not_evaluated_with_the_first_formula(zoo):
+    """The reference calls a 'custom' callback with `experiment` and `measurement` on every call
+    (project/base_project.py:380-383): a callback may branch on them.  One compiled program serves every experiment here,
+    so the Project traces the callback on EVERY experiment that carries the measure: equal traces compile, different ones
+    are refused (round 3 traced the first experiment only and used its formula for all)."""
+    from sysbio_modeling_amd.experiment import Experiment
+    from sysbio_modeling_amd.measurement import TimecourseMeasurement
+    from sysbio_modeling_amd.model import OdeModel
+    from sysbio_modeling_amd.project import Project
+    gm = zoo('michaelis_menten')
+    model = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, use_jit=False)
+    k = gm.n_sens
+    t = np.linspace(5.0, 100.0, 6)
+
+    def exps():
+        return [Experiment('exp_%d' % c, [TimecourseMeasurement('Both', 1.0 + 0.1 * t, t.copy())],
+                           experiment_settings={'dose': c}) for c in range(2)]
+
+    def same_map(model_sim, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        return par * model_sim[idx, 0] + model_sim[idx, 1], model_t[idx]
+
+    def same_jac(model_jac, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        return par * model_jac[idx, 0:k] + model_jac[idx, k:2 * k]
+
+    def weighted_map(model_sim, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        w = 1.0 + experiment.settings['dose']                 # a per-experiment weight
+        return w * model_sim[idx, 0] + model_sim[idx, 1], model_t[idx]
+
+    def weighted_jac(model_jac, model_t, experiment, measurement, par, use_experimental_timepoints=True):
+        idx = np.searchsorted(model_t, measurement.get_nonzero_measurements()[2])
+        w = 1.0 + experiment.settings['dose']
+        return w * model_jac[idx, 0:k] + model_jac[idx, k:2 * k]
+    settings = {'Global': list(gm.param_order)}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        proj = Project(model, exps(), settings, {'Both': ('custom', (2.0, same_map, same_jac))})
+        prog = proj._measurement_to_model_map['Both']
+        assert prog['program'] is not None and prog['variables'] == [0, 1]
+        with pytest.raises(ObservableError, match="exp_0.*exp_1|one compiled expression"):
+            Project(model, exps(), settings, {'Both': ('custom', (None, weighted_map, weighted_jac))})
