@@ -378,7 +378,8 @@ def _compact_side(name, c):
     if 'error' in c:
         return {"error": str(c['error'])[:80]}
     out = _pick(c, ('ms', 'value', 'seconds', 'fits_per_s', 'converged', 'starts', 'cost_median', 'failed_vectors',
-                    'n_gpus', 'scaling', 'macro_steps_per_vector', 'speedup_vs_one_core'))
+                    'n_gpus', 'scaling', 'macro_steps_per_vector', 'speedup_vs_one_core', 'vectors_per_rank',
+                    'gathered_norms_match_local_block_on_every_rank'))
     r = c.get('roofline') or (c.get('dopri45') or {}).get('roofline')
     if name == 'configs1' and isinstance(c.get('dopri45'), dict):
         out.update(_pick(c['dopri45'], ('ms', 'value', 'failed_vectors')))

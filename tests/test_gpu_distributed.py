@@ -145,7 +145,11 @@ def test_bench_multi_rank_line_on_one_gpu():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
+    assert len(lines[0]) < 4096                     # (the compact headline line; the full record is the side file)
     d = json.loads(lines[0])
+    with open(os.path.join(repo, d['full'])) as fh:
+        full = json.load(fh)
+    assert full['value'] == pytest.approx(d['value'], rel=1e-5) and 'configs3_sharded' in full['configs']
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 1e8 and d['config']['failed_vectors'] == 0
     assert d['ranks']['world_size_seen'] == 2 and d['ranks']['gathered_norms_match_local_block']
     c3 = d['configs']['configs3_sharded']
