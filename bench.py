@@ -301,6 +301,27 @@ def valu_roofline(key, k_ms, k_steps):
                     "close to the issue limit the kernel runs (valu_busy_fraction_pmc is the direct reading)"}
 
 
+def issue_roofline(key, k_ms, k_steps):
+    """Kernels at ONE wavefront per SIMD (the stiff integrators: three copies of a sensitivity column in registers): a
+    wavefront issues one instruction of any kind per four cycles, so the bound is instruction issue over ALL kinds.
+    achieved = (VALU + SALU + LDS wave-instructions per step, PMC) x steps per second -- branches, waits and vector-memory
+    instructions are not counted by these counters, so the figure understates what is issued; peak = 1024 SIMDs x
+    2.4 GHz / 4."""
+    c = _counters().get(key, {})
+    if not c.get('valu_insts_per_step') or c.get('waves_per_simd', 2) > 1.01:
+        return None
+    per_step = c['valu_insts_per_step'] + c.get('salu_insts_per_step', 0.0) + c.get('lds_insts_per_step', 0.0)
+    achieved = per_step * k_steps / (k_ms * 1e-3)
+    peak = N_SIMD * MAX_CLOCK_HZ / 4.0
+    return {"bound": "instruction_issue", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+            "frac": achieved / peak, "counted_insts_per_step": per_step, "valu_insts_per_step": c['valu_insts_per_step'],
+            "salu_insts_per_step": c.get('salu_insts_per_step'), "lds_insts_per_step": c.get('lds_insts_per_step'),
+            "any_inst_active_share_pmc": c.get('any_inst_active_share_of_wave_lifetime'),
+            "valu_busy_fraction_pmc": c.get('valu_busy_fraction'), "lds_conflict_share_pmc": c.get('lds_conflict_share'),
+            "source": c.get('source'),
+            "note": "one wavefront per SIMD: one instruction of any kind per 4 cycles (scripts/dev_latency_ubench.hip)"}
+
+
 _REAL_STDOUT = None
 T_START = time.perf_counter()
 
@@ -386,7 +407,11 @@ def _compact_side(name, c):
     rv = c.get('roofline_valu_issue') or (c.get('dopri45') or {}).get('roofline_valu_issue')
     if isinstance(r, dict):
         # the bound that applies: VALU issue where the byte model says > 1 or the PMC figures exist, else the byte model
-        if isinstance(rv, dict):
+        if r.get('bound') == 'instruction_issue':
+            out['roofline'] = {"bound": "instruction_issue", "frac": r.get('frac'), "valu_busy": r.get('valu_busy_fraction_pmc'),
+                               "any_inst_active": r.get('any_inst_active_share_pmc'),
+                               "hbm_model_frac": (c.get('roofline_hbm_model') or {}).get('frac')}
+        elif isinstance(rv, dict):
             out['roofline'] = {"bound": "valu_issue", "frac": rv.get('frac'), "valu_busy": rv.get('valu_busy_fraction_pmc'),
                                "hbm_model_frac": r.get('frac')}
         else:

@@ -298,8 +298,9 @@ def oracle_parity_pool(proj, a, thetas, R, J, picks, tight=True):
 # configs[4]: stiff 50-state cascade (2550 coupled ODEs), 4096 vectors
 # ---------------------------------------------------------------------------
 IEX_ORDER = 8
-STIFF_SETTING = ("extrapolated implicit Euler (SBM_IMPLICIT_EXTRAP, order 8: 36 implicit-Euler steps per macro step), "
-                 "LOCAL error control in the kernel at the method's default tolerances, ONE launch, no step count chosen")
+STIFF_SETTING = ("extrapolated implicit Euler (SBM_IMPLICIT_EXTRAP, order 8: 36 implicit-Euler steps per macro step; chain model: "
+                 "sequences side by side, persistent wavefronts), LOCAL error control in the kernel at the method's default "
+                 "tolerances, ONE launch, no step count chosen")
 STIFF_FIXED_SETTING = "implicit midpoint, 4096 + 8192 fixed steps, Richardson-extrapolated on the device (round 2's timed setting)"
 
 
@@ -402,7 +403,8 @@ def run_configs4(model, gm, dev, reps=3, cpu=True):
     ms_state = _events(torch, dev, lambda: dm.simulate_dev(P5, t5, None, opts, Y, st, ns, nr), reps)
     macro_state = int(ns.sum().item())
     dm.sens_dev(P5, t5, None, opts, Y, S, st, ns, nr)      # (Y of the sensitivity pass again, for the parity check)
-    evals = 2.9      # Newton evaluations per Euler step (measured: profiles/r03, developer build SBM_IEX_COUNT_NEWTON)
+    evals = 2.9      # Newton evaluations per Euler step (measured on sbm_iex_kernel: profiles/r03, SBM_IEX_COUNT_NEWTON; the
+    #                  sequences-side-by-side kernel follows the same stopping rule per sequence)
     F, formula = B.flops_per_step(gm5, 'implicit_euler', evals_per_step=evals)
     out = {"workload": "configs[4]: stiff50 (50 states, 50 sensitivity parameters: 2550 coupled ODEs, rates spanning "
                        "1e6), 4096 vectors, 16 output times, " + STIFF_SETTING + " (rtol %g, atol %g)" % (tol['rtol'], tol['atol']),
@@ -413,7 +415,7 @@ def run_configs4(model, gm, dev, reps=3, cpu=True):
            "vectors_per_s": V / (ms * 1e-3), "launches_per_pass": 1, "failed_vectors": failed,
            "macro_steps_per_vector": macro / V, "state_only": {"ms": ms_state, "macro_steps_per_vector": macro_state / V},
            "parity_of_timed_pass": stiff_golden_parity(gdir, Pn, Y, S),
-           "roofline": B.hbm_roofline("sbm_iex_kernel<stiff50>", 'iex_stiff50', ms, euler, 2 * 8 * 2550,
+           "roofline": B.hbm_roofline("sbm_iex_seq_kernel<stiff50, rotated columns>", 'iex_stiff50', ms, euler, 2 * 8 * 2550,
                                       "SURVEY.md section 8(d): 40 800 B per step under the state-streaming model (a "
                                       "streaming integrator reads and writes the augmented state once per implicit-Euler "
                                       "step); a fraction above 1 says only that a streaming integrator could not run this "
@@ -422,6 +424,15 @@ def run_configs4(model, gm, dev, reps=3, cpu=True):
     rv = B.valu_roofline('iex_stiff50', ms, euler)
     if rv:
         out["roofline_valu_issue"] = rv
+    ri = B.issue_roofline('iex_stiff50', ms, euler)
+    if ri:
+        # the bound that applies to a kernel at ONE wavefront per SIMD: a wavefront issues one instruction of ANY kind per
+        # four cycles, so vector, scalar and LDS instructions queue behind each other (the byte model's fraction above 1
+        # is kept as roofline_hbm_model: it says a streaming integrator could not run this fast, nothing else)
+        out["roofline_hbm_model"] = out["roofline"]
+        out["roofline"] = dict(ri, achieved_fp64=out["roofline_hbm_model"].get("achieved_fp64"),
+                               traffic=out["roofline_hbm_model"].get("traffic"), kernel=out["roofline_hbm_model"].get("kernel"),
+                               kernel_ms=ms)
     # round 2's timed setting beside it: the hand-chosen fixed-step Richardson pair
     try:
         fx = run_configs4_fixed(model, gm, dev, reps=reps, cpu=False, setup=(gm5, m5, Pn, P5, t_np, t5, gdir))

@@ -31,7 +31,7 @@ KEYS = {
     'sens_rowgroup_cascade20_dopri45': ('headline', r'sbm_sens_rowgroup_kernel<.*, 1>', ('headline', 'steps_per_pass'), 1, 'cascade20'),
     'state_packed_cascade20_dopri45': ('configs1', r'sbm_state_packed_kernel<.*, 1, ', ('configs1', 'dopri45', 'steps'), 1, 'cascade20'),
     'state_packed_cascade20_rk4_fixed_4096': ('configs1', r'sbm_state_packed_kernel<.*, 0, ', ('configs1', 'rk4_fixed_4096', 'steps'), 1, 'cascade20'),
-    'iex_stiff50': ('configs4', r'sbm_iex_kernel', ('configs4', 'euler_steps'), 1, 'stiff50'),
+    'iex_stiff50': ('configs4', r'sbm_iex(_seq)?_kernel', ('configs4', 'euler_steps'), 1, 'stiff50'),
     'imid_stiff50': ('configs4_fixed', r'sbm_imid_kernel', ('configs4_fixed', 'steps'), None, 'stiff50'),
     'lm_step': ('fit', r'k_lm_step', None, None, 'core'),
     'lm_trust_step': ('fit', r'k_lm_trust', None, None, 'core'),
@@ -166,6 +166,11 @@ def main(src, dst):
                         out['waves_per_simd'] = wps
                         out['valu_active_share_of_wave_lifetime'] = av['total'] / wc['total']
                         out['valu_busy_fraction'] = min(1.0, av['total'] / wc['total'] * wps)
+            if 'SQ_INSTS_SALU' in e and steps_pass:
+                out['salu_insts_per_step'] = e['SQ_INSTS_SALU']['mean_per_launch'] * lpp / steps_pass
+            if 'SQ_ACTIVE_INST_ANY' in e and e.get('SQ_WAVE_CYCLES', {}).get('total'):
+                # share of a wavefront's lifetime in which it has an instruction of ANY kind in flight
+                out['any_inst_active_share_of_wave_lifetime'] = e['SQ_ACTIVE_INST_ANY']['total'] / e['SQ_WAVE_CYCLES']['total']
             if 'SQ_LDS_BANK_CONFLICT' in e and e.get('SQ_LDS_IDX_ACTIVE', {}).get('total'):
                 out['lds_conflict_share'] = e['SQ_LDS_BANK_CONFLICT']['total'] / e['SQ_LDS_IDX_ACTIVE']['total']
                 if 'SQ_INSTS_LDS' in e and steps_pass:
