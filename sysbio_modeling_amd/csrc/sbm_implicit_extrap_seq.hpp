@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
     double H = a.opts.h0 > 0.0 ? a.opts.h0 : 1e-3 * (t_span > 0.0 ? t_span : 1.0);
     double colmax = 0.0;
     bool after_reject = false;
+    float cest = __builtin_inff();      // contraction constant of this lane group's Newton iterations (phase A)
 
     for (int io = 0; io < glen; ++io) {
       const double target = tg[io];
@@ -331,7 +332,20 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
                 else if (rr <= 1.0f) mode = MODE_DONE;
                 else if (it > 0 && rr < 0.25f * r_prev && rr * rr * (rr / (r_prev * r_prev)) <= 0.1f) mode = MODE_FINAL;
                 else if (it >= 2 && rr >= 0.5f * r_prev && rr <= 1.0e3f) mode = MODE_FINAL;
+                // One update may do.  Newton contracts quadratically, update_{k+1} ~ c update_k^2 (in tolerances), and c --
+                // a property of the equations and the step size -- changes slowly along a trajectory: the second update
+                // of an earlier Euler step of this group measured it (cest; refreshed in the first slot of every macro
+                // step, where two updates are always made).  If c update_1^2 predicts a second update below a fortieth
+                // of the tolerance, the iterate after the FIRST update is the converged state: the evaluation that
+                // follows is the final one.  (Nine of the 27 passes of a macro step were second updates.)
+                else if (it == 0 && s > 0 && cest * rr * rr <= 0.025f) mode = MODE_FINAL;
+                if (it == 1 && r_prev > 1.0f) {
+                  const float c = rr / (r_prev * r_prev);
+                  cest = cest < 3.0e38f ? fmaxf(c, 0.7f * cest) : c;
+                }
                 r_prev = rr;
+                // without sensitivities nobody wants the matrices at the converged state
+                if (!with_sens && mode == MODE_FINAL) mode = MODE_DONE;
               }
               if (with_sens && mode_in != MODE_DONE && mode == MODE_DONE) {
                 // the group has finished this Euler step: tw holds the matrices of its last evaluation

@@ -11,12 +11,16 @@
 //     16 ct + (l & 15).  That layout is at the same time the B-operand layout of the next product: k-step s of a tile
 //     wants B[k = 4 s + (l >> 4)][n = l & 15], i.e. register s.  So a Runge-Kutta stage vector goes into the product
 //     exactly as it stands -- no transposition, no LDS round trip for S;
-//   * J_y is handed over as a dense 16 RT x 16 RT tile image in LDS: row lane i drops its non-zeros at [i][column]
-//     (the rest stays zero), and every lane fetches its A operands A[i = l & 15][k = 4 s + (l >> 4)] from there --
-//     4 RT^2 loads of 8 bytes per stage, reused for all column tiles; the row stride is padded by two doubles, which
-//     makes the 32 lanes of an LDS access group hit 32 different bank pairs, and the rows of tile row rt are shifted
-//     by rt columns (the padding has room for RT - 1), so that the row lanes i and i + 16, which write the same column of a
-//     dense J_y at a distance of 16 x 34 doubles = 0 mod 32 bank pairs, do not collide either;
+//   * J_y is handed over as a dense 16 RT x 16 RT tile image in LDS, stored COLUMN-major (JD[k][i], column stride LDJ ==
+//     16 mod 32 doubles): row lane i drops its non-zeros at [column][i] (the rest stays zero), and every lane fetches its
+//     A operands A[i = l & 15][k = 4 s + (l >> 4)] from there -- 4 RT^2 loads of 8 bytes per stage, reused for all column
+//     tiles.  The banking rules (MI355X_MICROARCH.md, LDS): a ds_read_b64 is served in the lane groups 0-31 / 32-63 on
+//     banks (a / 4) mod 64 -- the 32 lanes (l & 15, l >> 4 in {0, 1}) read doubles (l >> 4) LDJ + (l & 15) + const, i.e.
+//     {0..15} and {16..31} mod 32: conflict-free; a ds_write_b64 in groups of 16 consecutive lanes on banks (a / 4) mod 32
+//     -- the 16 row lanes i write doubles c_s(i) LDJ + i, i.e. i mod 16 whatever their columns: conflict-free.  (Round 3
+//     stored the image row-major with a row stride of MP + 2: reads conflict-free, but the row lanes i and i + 8 of a
+//     dense J_y -- slot s is the same column in every row -- wrote the same bank pair: a third of the kernel's LDS cycles
+//     were conflicts, profiles/r03/dense_pmc_summary.json.)
 //   * J_p is the C operand: the accumulators start from the dense [row][column] image the row lanes fill.
 //
 // Cost per stage: 4 RT^2 CT MFMAs of 64 cycles whatever the sparsity of J_y -- cascade20 (RT = 2, CT = 3): 48 MFMAs =
@@ -32,12 +36,13 @@ template <class M, int CT>
 struct SbmMfmaShared {
   static constexpr int RT = (M::NV + 15) / 16;
   static constexpr int MP = 16 * RT;               // padded rows (= padded k range)
-  static constexpr int LDJ = MP + (RT > 3 ? 6 : 2);   // row stride of the J_y image (== 2 mod 4: conflict-free A-operand reads; >= MP + RT - 1)
+  static constexpr int LDJ = (MP % 32 == 16) ? MP : MP + 16;   // COLUMN stride of the J_y image JD[k][i]: == 16 mod 32
   static constexpr int NC = 16 * CT;               // columns of this wavefront's chunk
   static constexpr int LDA = (NC % 32 == 16) ? NC : NC + 16;   // row stride of the J_p image: == 16 mod 32
   double Y[64];
-  alignas(16) double JD[MP * LDJ + 2];             // J_y, dense, zero where structurally zero (+ spare slot)
-  alignas(16) double A[MP * LDA + 2];              // J_p columns of this chunk (+ spare slot)
+  alignas(16) double JD[MP * LDJ + 64];            // J_y, dense, zero where structurally zero (+ one spare slot per lane:
+                                                   //  lanes without a row / slot must not all write ONE address)
+  alignas(16) double A[MP * LDA + 64];             // J_p columns of this chunk (+ one spare slot per lane)
 };
 
 template <class M, int CT>
@@ -96,7 +101,7 @@ struct MfmaSystem {
 #pragma unroll
       for (int kt = 0; kt < RT; ++kt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) aop[rt][kt][s] = sh->JD[(16 * rt + lr) * Sh::LDJ + 16 * kt + 4 * s + lq + rt];
+        for (int s = 0; s < 4; ++s) aop[rt][kt][s] = sh->JD[(16 * kt + 4 * s + lq) * Sh::LDJ + 16 * rt + lr];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -173,8 +178,8 @@ __global__ void __launch_bounds__(64, SbmMfmaPlan<M>::MIN_WAVES) sbm_sens_mfma_k
   const int lane = threadIdx.x;
   const int chunk = NCH > 1 ? (int)blockIdx.y : 0;
   const int cbase = chunk * 16 * CT;
-  for (int i = lane; i < Sh::MP * Sh::LDJ + 2; i += 64) sh.JD[i] = 0.0;
-  for (int i = lane; i < Sh::MP * Sh::LDA + 2; i += 64) sh.A[i] = 0.0;
+  for (int i = lane; i < Sh::MP * Sh::LDJ + 64; i += 64) sh.JD[i] = 0.0;
+  for (int i = lane; i < Sh::MP * Sh::LDA + 64; i += 64) sh.A[i] = 0.0;
   sh.Y[lane] = 0.0;
 
   Sys sys;
@@ -192,12 +197,12 @@ __global__ void __launch_bounds__(64, SbmMfmaPlan<M>::MIN_WAVES) sbm_sens_mfma_k
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJY; ++s) {
     const int c = M::rl_jycol(s, row);
-    sys.jdpos[s] = (has_row && c >= 0) ? row * Sh::LDJ + c + (row >> 4) : Sh::MP * Sh::LDJ + 1;   // else: spare slot
+    sys.jdpos[s] = (has_row && c >= 0) ? c * Sh::LDJ + row : Sh::MP * Sh::LDJ + lane;   // [column][row]; else: this lane's spare slot
   }
 #pragma unroll
   for (int s = 0; s < M::RL_MAXJP; ++s) {
     const int lc = M::rl_jpcol(s, row) - cbase;
-    sys.apos[s] = (has_row && lc >= 0 && lc < 16 * CT && lc + cbase < NK) ? row * Sh::LDA + lc : Sh::MP * Sh::LDA + 1;
+    sys.apos[s] = (has_row && lc >= 0 && lc < 16 * CT && lc + cbase < NK) ? row * Sh::LDA + lc : Sh::MP * Sh::LDA + lane;
   }
   __syncthreads();
 
