@@ -1345,8 +1345,10 @@ struct SbmRowGroupShared {
   static constexpr int ZPOS = L::RG_RPG * LS;   // a slot of H that stays zero (absent halo terms)
   static constexpr int RPL = (M::NV + 63) / 64;   // state rows per lane (rows lane, lane + 64, ...)
   double Y[64 * RPL];                    // stage state, one component per (row lane, r)
-  alignas(16) double JYL[NROWS * L::RG_JYS + 2];   // J_y coefficients [row][term] (+ spare slot)
-  alignas(16) double A[L::RG_RPG * LS + 2];        // J_p entries (+ spare slot); idle / padded slots stay 0
+  // (+ one spare slot PER LANE for the lanes without a row / the slots without an entry: 44 idle lanes storing to one
+  //  address are a 16-way conflict on every store of the hand-over, round 4's PMC pass)
+  alignas(16) double JYL[NROWS * L::RG_JYS + 64];  // J_y coefficients [row][term]
+  alignas(16) double A[L::RG_RPG * LS + 64];       // J_p entries; idle / padded slots stay 0
   alignas(16) double H[L::RG_RPG * LS + 4];        // published rows of the stage vector (+ zero slot)
 };
 
@@ -1502,9 +1504,9 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
 
   constexpr int NROWS = Sh::NROWS;
   constexpr int LS = Sh::LS;
-  for (int i = lane; i < RPG * LS + 2; i += 64) sh.A[i] = 0.0;
+  for (int i = lane; i < RPG * LS + 64; i += 64) sh.A[i] = 0.0;
   for (int i = lane; i < RPG * LS + 4; i += 64) sh.H[i] = 0.0;
-  for (int i = lane; i < NROWS * L::RG_JYS + 2; i += 64) sh.JYL[i] = 0.0;
+  for (int i = lane; i < NROWS * L::RG_JYS + 64; i += 64) sh.JYL[i] = 0.0;
 #pragma unroll
   for (int r = 0; r < RPL; ++r) sh.Y[lane + 64 * r] = 0.0;
 
@@ -1528,16 +1530,16 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJY; ++s) {
       const int jp_ = L::rg_jypos(s, row);
-      sys.jypos[r][s] = (has_row && jp_ < NPAD * L::RG_JYS) ? jp_ : NROWS * L::RG_JYS + 1;   // else: spare slot
+      sys.jypos[r][s] = (has_row && jp_ < NPAD * L::RG_JYS) ? jp_ : NROWS * L::RG_JYS + lane;   // else: this lane's spare slot
     }
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) {
       if constexpr (NCH == 1 && RPL == 1) {
         const int ap = M::rl_apos(s, row);                      // row*64 + column; unused slots carry MNV*64
-        sys.apos[r][s] = (has_row && ap < MNV * 64) ? L::rg_pos(ap >> 6, ap & 63) : RPG * LS + 1;
+        sys.apos[r][s] = (has_row && ap < MNV * 64) ? L::rg_pos(ap >> 6, ap & 63) : RPG * LS + lane;
       } else {
         const int lc = M::rl_jpcol(s, row) - cbase;             // column within this chunk (unused slots: -1)
-        sys.apos[r][s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? L::rg_pos(row, lc) : RPG * LS + 1;
+        sys.apos[r][s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? L::rg_pos(row, lc) : RPG * LS + lane;
       }
     }
   }
