@@ -41,6 +41,9 @@
 #define SBM_SEQ_PF 4      // Euler steps a table is loaded ahead of its use (rotated columns)
 #endif
 
+// 1 / j for the sequence lengths (H / j formed as one product, the same in both phases)
+__constant__ double SBM_IEX_RJ[SBM_IEX_KMAX + 2] = {1.0, 1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11};
+
 template <class M>
 struct SbmIexSeqPlan {
   static constexpr int LPG = 16;                                 // lanes per group = one DPP row
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
     long long n_acc = 0, n_rej = 0;
 #ifdef SBM_SEQ_PROFILE
     long long prof_a = 0, prof_b = 0;
-#if defined(SBM_SEQ_PROFILE2) || defined(SBM_SEQ_PROFILE3) || defined(SBM_SEQ_PROFILE4) || defined(SBM_SEQ_PROFILE5)
+#if defined(SBM_SEQ_PROFILE2) || defined(SBM_SEQ_PROFILE3) || defined(SBM_SEQ_PROFILE4) || defined(SBM_SEQ_PROFILE5) || defined(SBM_SEQ_PROFILE6) || defined(SBM_SEQ_PROFILE7) || defined(SBM_SEQ_PROFILE8)
     long long prof_s = 0;
 #endif
     const long long prof_t0 = __builtin_readcyclecounter();
@@ -223,19 +226,19 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
           double ya[RPG], yp[RPG], yp2[RPG], yp3[RPG];
 #pragma unroll
           for (int r = 0; r < RPG; ++r) ya[r] = yp[r] = yp2[r] = yp3[r] = 0.0;
+#ifdef SBM_SEQ_PROFILE7
+          asm volatile("" ::: "memory");
+          prof_s += __builtin_readcyclecounter() - tp0;
+#endif
 #pragma unroll 1
           for (int s = 0; s <= K && rc == SBM_OK; ++s) {
             const bool in_first = s < j_first;
             const int jc = in_first ? j_first : j_second;       // the sequence this group works on (0: none)
             const int m = in_first ? s : s - j_first;           // its Euler step
             const bool act = grp_on && jc > 0 && m < jc;
-            const double hj = Hs / (double)(jc > 0 ? jc : 1);
+            const double hj = Hs * SBM_IEX_RJ[jc];        // (the same product in phase B: the two must agree to the bit)
             if (m == 0) {
-              // a sequence begins: its result so far is T of the sequence before (if any); history from (y_n, slope)
-              if (grp_on && !in_first) {
-#pragma unroll
-                for (int r = 0; r < RPG; ++r) sh.TG[j_first - 1][gl * RPG + r] = ya[r];
-              }
+              // a sequence begins: history from (y_n, slope of the last macro step)
 #pragma unroll
               for (int r = 0; r < RPG; ++r) {
                 const int row = hasA[r] ? gl * RPG + r : 0;
@@ -244,14 +247,13 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
                 yp2[r] = yp3[r] = 0.0;
               }
             }
+            // predictor: the polynomial through the last 2 / 3 / 4 points of the sequence, as one combination with the
+            // coefficients of the group's step number (no select per row)
+            const double c0 = m < 2 ? 2.0 : (m == 2 ? 3.0 : 4.0), c1 = m < 2 ? -1.0 : (m == 2 ? -3.0 : -6.0);
+            const double c2 = m < 2 ? 0.0 : (m == 2 ? 1.0 : 4.0), c3 = m < 3 ? 0.0 : -1.0;
             double yb[RPG];
 #pragma unroll
-            for (int r = 0; r < RPG; ++r) {
-              const double lin = fma(2.0, ya[r], -yp[r]);
-              const double quad = fma(3.0, ya[r] - yp[r], yp2[r]);
-              const double cub = fma(4.0, ya[r] + yp2[r], fma(-6.0, yp[r], -yp3[r]));
-              yb[r] = m < 2 ? lin : (m == 2 ? quad : cub);
-            }
+            for (int r = 0; r < RPG; ++r) yb[r] = fma(c0, ya[r], fma(c1, yp[r], fma(c2, yp2[r], c3 * yp3[r])));
             const double tm = fma((double)(m + 1), hj, t);
             // table of Euler step m of sequence jc, this lane's rows
             double* const trow = ROT ? tblock + (size_t)((jc * (jc - 1)) / 2 + m) * Pl::ROT_STEP_DOUBLES + (size_t)gl * RPG * 2
@@ -260,6 +262,10 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
             float r_prev = 0.f;
 #pragma unroll 1
             for (int it = 0;; ++it) {
+#ifdef SBM_SEQ_PROFILE6
+              const long long tq6a = __builtin_readcyclecounter();
+              asm volatile("" ::: "memory");
+#endif
 #pragma unroll
               for (int r = 0; r < RPG; ++r) sh.YG[grp][gl * RPG + r] = yb[r];
               Stepper::fence();
@@ -300,6 +306,15 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
                 for (int q = 0; q < M::RL_MAXJP; ++q) tw[r * W + 2 + q] = jp[q];
               }
               const int mode_in = mode;
+#ifdef SBM_SEQ_PROFILE6
+              asm volatile("" ::: "memory");
+              const long long tq6 = __builtin_readcyclecounter();
+              prof_s += tq6 - tq6a;
+#endif
+#ifdef SBM_SEQ_PROFILE8
+              const long long tq8 = __builtin_readcyclecounter();
+              asm volatile("" ::: "memory");
+#endif
               if (__builtin_amdgcn_ballot_w64(mode == MODE_ITER) == 0ull) {
                 // every group still at work only wanted its matrices at the converged state: no update, no test
                 if (with_sens && mode == MODE_FINAL) {
@@ -317,55 +332,65 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
               Stepper::template chain_level<0x114, 0xf>(pa, pb);    // row_shr:4
               Stepper::template chain_level<0x118, 0xf>(pa, pb);    // row_shr:8
               const double din = Stepper::template dpp_f64<0x111, 0xf>(pb, 0.0);
+              // (update, test and decisions WITHOUT branches and divisions: at one wavefront per SIMD every exec-masked
+              // region costs its scalar bookkeeping plus a branch bubble -- round 4's first version spent a dozen of them
+              // and two IEEE divisions per pass here)
               float rmax = 0.f;
               const bool upd = mode == MODE_ITER;
 #pragma unroll
               for (int r = 0; r < RPG; ++r) {
                 const double d = fma(Ap[r], din, Bp[r]);
                 yb[r] = upd ? yb[r] - d : yb[r];
-                rmax = fmaxf(rmax, hasA[r] ? sbm_nan_to_inf((float)fabs(d) * __builtin_amdgcn_rcpf((float)fmax(fma(nrtol, fabs(yb[r]), natol), 1e-30))) : 0.f);
+                const float q = (float)fabs(d) * __builtin_amdgcn_rcpf((float)fmax(fma(nrtol, fabs(yb[r]), natol), 1e-30));
+                const float qi = sbm_nan_to_inf(q);
+                rmax = fmaxf(rmax, hasA[r] ? qi : 0.f);                   // (q formed unconditionally: a select, not a branch)
               }
               const float rr = sbm_row16_max(rmax);
-              bool bad = false;
-              if (upd) {
-                if (!(rr < 3.0e38f)) bad = true;
-                else if (rr <= 1.0f) mode = MODE_DONE;
-                else if (it > 0 && rr < 0.25f * r_prev && rr * rr * (rr / (r_prev * r_prev)) <= 0.1f) mode = MODE_FINAL;
-                else if (it >= 2 && rr >= 0.5f * r_prev && rr <= 1.0e3f) mode = MODE_FINAL;
-                // One update may do.  Newton contracts quadratically, update_{k+1} ~ c update_k^2 (in tolerances), and c --
-                // a property of the equations and the step size -- changes slowly along a trajectory: the second update
-                // of an earlier Euler step of this group measured it (cest; refreshed in the first slot of every macro
-                // step, where two updates are always made).  If c update_1^2 predicts a second update below a fortieth
-                // of the tolerance, the iterate after the FIRST update is the converged state: the evaluation that
-                // follows is the final one.  (Nine of the 27 passes of a macro step were second updates.)
-                else if (it == 0 && s > 0 && cest * rr * rr <= 0.025f) mode = MODE_FINAL;
-                if (it == 1 && r_prev > 1.0f) {
-                  const float c = rr / (r_prev * r_prev);
-                  cest = cest < 3.0e38f ? fmaxf(c, 0.7f * cest) : c;
-                }
-                r_prev = rr;
-                // without sensitivities nobody wants the matrices at the converged state
-                if (!with_sens && mode == MODE_FINAL) mode = MODE_DONE;
+              const float rp2 = r_prev * r_prev;
+              const bool fin = rr < 3.0e38f;
+              const bool conv = rr <= 1.0f;
+              const bool rate = (it > 0) & (rr < 0.25f * r_prev) & (rr * rr * rr <= 0.1f * rp2);
+              const bool stall = (it >= 2) & (rr >= 0.5f * r_prev) & (rr <= 1.0e3f);
+              // One update may do.  Newton contracts quadratically, update_{k+1} ~ c update_k^2 (in tolerances), and c --
+              // a property of the equations and the step size -- changes slowly along a trajectory: the second update of
+              // an earlier Euler step of this group measured it (cest; refreshed in the first slot of every macro step,
+              // where two updates are always made).  If c update_1^2 predicts a second update below a fortieth of the
+              // tolerance, the iterate after the FIRST update is the converged state.
+              const bool one = (it == 0) & (s > 0) & (cest * rr * rr <= 0.025f);
+              const int next_mode = conv ? MODE_DONE : ((rate | stall | one) ? MODE_FINAL : MODE_ITER);
+              const bool bad = upd & !fin;
+              mode = (upd & fin) ? next_mode : mode;
+              {
+                const float c = rr * __builtin_amdgcn_rcpf(fmaxf(rp2, 1e-30f));
+                const float cnew = cest < 3.0e38f ? fmaxf(c, 0.7f * cest) : c;
+                cest = (upd & fin & (it == 1) & (r_prev > 1.0f)) ? cnew : cest;
               }
+              r_prev = upd ? rr : r_prev;
+              // without sensitivities nobody wants the matrices at the converged state
+              mode = (!with_sens & (mode == MODE_FINAL)) ? MODE_DONE : mode;
               if (with_sens && mode_in != MODE_DONE && mode == MODE_DONE) {
                 // the group has finished this Euler step: tw holds the matrices of its last evaluation
                 store_table(trow, tw);
               }
+#ifdef SBM_SEQ_PROFILE8
+              asm volatile("" ::: "memory");
+              prof_s += __builtin_readcyclecounter() - tq8;
+#endif
               if (__builtin_amdgcn_ballot_w64(bad) != 0ull) { rc = SBM_NON_FINITE; break; }
               if (__builtin_amdgcn_ballot_w64(mode != MODE_DONE) == 0ull) break;
               if (it >= 8) { rc = SBM_NEWTON_FAIL; break; }      // eight updates, as newton_rate<8>
             }
-            if (act) {
+            // a sequence that has made its last step leaves T_j; every group moves its history on (a group without work
+            // carries values nobody reads: no select per row)
+            if (act && m == jc - 1) {
 #pragma unroll
-              for (int r = 0; r < RPG; ++r) { yp3[r] = yp2[r]; yp2[r] = yp[r]; yp[r] = ya[r]; ya[r] = yb[r]; }
+              for (int r = 0; r < RPG; ++r) sh.TG[jc - 1][gl * RPG + r] = yb[r];
             }
+#pragma unroll
+            for (int r = 0; r < RPG; ++r) { yp3[r] = yp2[r]; yp2[r] = yp[r]; yp[r] = ya[r]; ya[r] = yb[r]; }
           }
           if (rc == SBM_OK) {
-            // the last sequence of every group, then the two extrapolations on the row lanes
-            if (j_second > 0) {     // (the first sequence's result went there when the group switched, slot j_first <= K)
-#pragma unroll
-              for (int r = 0; r < RPG; ++r) sh.TG[j_second - 1][gl * RPG + r] = ya[r];
-            }
+            // the two extrapolations on the row lanes
             Stepper::fence();
 #pragma unroll 1
             for (int j = 1; j <= K; ++j) {
@@ -429,7 +454,7 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
 #endif
 #pragma unroll
               for (int i = 0; i < NV; ++i) zs[i] = sh.ZN[i * ZS + zl];
-              h = Hs / (double)j;
+              h = Hs * SBM_IEX_RJ[j];
 #ifdef SBM_SEQ_PROFILE5
               asm volatile("" ::: "memory");
               prof_s += __builtin_readcyclecounter() - tq5;
@@ -534,7 +559,7 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
                 if (m == 0) {
 #pragma unroll
                   for (int i = 0; i < NV; ++i) zs[i] = sh.ZN[i * ZS + zl];
-                  h = Hs / (double)j;
+                  h = Hs * SBM_IEX_RJ[j];
                 }
                 // this step's table into the LDS tables im_sens_tri reads (row lane i: row i); its registers take the
                 // table of the step PF ahead
@@ -652,7 +677,7 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
 #ifdef SBM_SEQ_PROFILE      // developer build: kilocycles of phase A in n_steps, of phase B in n_reject, of the trajectory in status
     n_acc = prof_a >> 10;
     n_rej = prof_b >> 10;
-#if defined(SBM_SEQ_PROFILE2) || defined(SBM_SEQ_PROFILE3) || defined(SBM_SEQ_PROFILE4) || defined(SBM_SEQ_PROFILE5)
+#if defined(SBM_SEQ_PROFILE2) || defined(SBM_SEQ_PROFILE3) || defined(SBM_SEQ_PROFILE4) || defined(SBM_SEQ_PROFILE5) || defined(SBM_SEQ_PROFILE6) || defined(SBM_SEQ_PROFILE7) || defined(SBM_SEQ_PROFILE8)
     n_acc = prof_s >> 10;      // the column step (2) / the accumulation (3) alone instead of phase A
 #endif
     status = (int)((__builtin_readcyclecounter() - prof_t0) >> 10);
