@@ -41,8 +41,20 @@
 #define SBM_SEQ_PF 4      // Euler steps a table is loaded ahead of its use (rotated columns)
 #endif
 
-// 1 / j for the sequence lengths (H / j formed as one product, the same in both phases)
-__constant__ double SBM_IEX_RJ[SBM_IEX_KMAX + 2] = {1.0, 1.0, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10, 1.0 / 11};
+// 1 / j for the sequence lengths j = 1 .. 8 (H / j formed as one product, the same in both phases), as a select chain on
+// literals: j differs from lane group to lane group in phase A, and a table look-up with a per-lane index is a vector
+// memory load -- a microsecond per slot (measured: +4 ms per pass of configs[4])
+__device__ __forceinline__ double sbm_iex_rj(int j) {
+  double r = 1.0;
+  r = j == 2 ? 1.0 / 2 : r;
+  r = j == 3 ? 1.0 / 3 : r;
+  r = j == 4 ? 1.0 / 4 : r;
+  r = j == 5 ? 1.0 / 5 : r;
+  r = j == 6 ? 1.0 / 6 : r;
+  r = j == 7 ? 1.0 / 7 : r;
+  r = j == 8 ? 1.0 / 8 : r;
+  return r;
+}
 
 template <class M>
 struct SbmIexSeqPlan {
@@ -236,7 +248,7 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
             const int jc = in_first ? j_first : j_second;       // the sequence this group works on (0: none)
             const int m = in_first ? s : s - j_first;           // its Euler step
             const bool act = grp_on && jc > 0 && m < jc;
-            const double hj = Hs * SBM_IEX_RJ[jc];        // (the same product in phase B: the two must agree to the bit)
+            const double hj = Hs * sbm_iex_rj(jc);        // (the same product in phase B: the two must agree to the bit)
             if (m == 0) {
               // a sequence begins: history from (y_n, slope of the last macro step)
 #pragma unroll
@@ -454,7 +466,7 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
 #endif
 #pragma unroll
               for (int i = 0; i < NV; ++i) zs[i] = sh.ZN[i * ZS + zl];
-              h = Hs * SBM_IEX_RJ[j];
+              h = Hs * sbm_iex_rj(j);
 #ifdef SBM_SEQ_PROFILE5
               asm volatile("" ::: "memory");
               prof_s += __builtin_readcyclecounter() - tq5;
@@ -559,7 +571,7 @@ __global__ void __launch_bounds__(64) sbm_iex_seq_kernel(sbm_kernel_args a, doub
                 if (m == 0) {
 #pragma unroll
                   for (int i = 0; i < NV; ++i) zs[i] = sh.ZN[i * ZS + zl];
-                  h = Hs * SBM_IEX_RJ[j];
+                  h = Hs * sbm_iex_rj(j);
                 }
                 // this step's table into the LDS tables im_sens_tri reads (row lane i: row i); its registers take the
                 // table of the step PF ahead
