@@ -38,7 +38,7 @@ KEYS = {
     'lm_update': ('fit', r'k_lm_update', None, None, 'core'),
     'assemble': ('headline', r'k_assemble', None, 1, 'core'),
     'sens_rowgroup_cascade20_dop853': ('dop853', r'sbm_sens_rowgroup_kernel<.*RG2, 5>', ('dop853', 'steps'), 1, 'cascade20'),
-    'dense20_valu': ('dense', r'sbm_sens_rowlane_kernel', ('dense', 'valu', 'steps'), 1, 'dense20'),
+    'dense20_valu': ('dense', r'sbm_sens_row(lane|group)_kernel', ('dense', 'valu', 'steps'), 1, 'dense20'),
     'dense20_mfma': ('dense', r'sbm_sens_mfma_kernel', ('dense', 'mfma', 'steps'), 1, 'dense20'),
 }
 
