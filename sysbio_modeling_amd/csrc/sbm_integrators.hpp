@@ -1335,6 +1335,14 @@ __global__ void __launch_bounds__(64) sbm_state_packed_kernel(sbm_kernel_args a)
 // sequence, nothing exchanged.  Chunk 0 stores the state; status / step counts are combined with atomicMax
 // (the launcher zeroes them first).
 // ===========================================================================
+#ifndef SBM_RG_LANE_SPARE
+#define SBM_RG_LANE_SPARE 0
+#endif
+#if SBM_RG_LANE_SPARE
+#define SBM_RG_SPARE(lane) (lane)
+#else
+#define SBM_RG_SPARE(lane) 1
+#endif
 template <class M, class L>
 struct SbmRowGroupShared {
   // JYL rows: G groups of RPG (the last one padded), then one more all-padding group for the idle
@@ -1530,16 +1538,16 @@ __global__ void __launch_bounds__(64, SBM_RG_MIN_WAVES) sbm_sens_rowgroup_kernel
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJY; ++s) {
       const int jp_ = L::rg_jypos(s, row);
-      sys.jypos[r][s] = (has_row && jp_ < NPAD * L::RG_JYS) ? jp_ : NROWS * L::RG_JYS + lane;   // else: this lane's spare slot
+      sys.jypos[r][s] = (has_row && jp_ < NPAD * L::RG_JYS) ? jp_ : NROWS * L::RG_JYS + SBM_RG_SPARE(lane);   // else: spare slot
     }
 #pragma unroll
     for (int s = 0; s < M::RL_MAXJP; ++s) {
       if constexpr (NCH == 1 && RPL == 1) {
         const int ap = M::rl_apos(s, row);                      // row*64 + column; unused slots carry MNV*64
-        sys.apos[r][s] = (has_row && ap < MNV * 64) ? L::rg_pos(ap >> 6, ap & 63) : RPG * LS + lane;
+        sys.apos[r][s] = (has_row && ap < MNV * 64) ? L::rg_pos(ap >> 6, ap & 63) : RPG * LS + SBM_RG_SPARE(lane);
       } else {
         const int lc = M::rl_jpcol(s, row) - cbase;             // column within this chunk (unused slots: -1)
-        sys.apos[r][s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? L::rg_pos(row, lc) : RPG * LS + lane;
+        sys.apos[r][s] = (has_row && lc >= 0 && lc < C * CPL && lc + cbase < NK) ? L::rg_pos(row, lc) : RPG * LS + SBM_RG_SPARE(lane);
       }
     }
   }
