@@ -420,7 +420,10 @@ def _compact_side(name, c):
             out['roofline']['fp64_frac'] = r['achieved_fp64'].get('frac')
     par = c.get('parity_of_timed_pass') or (c.get('cpu_baseline') or {}).get('parity_of_timed_pass')
     if isinstance(par, dict):
-        out['parity'] = {k: v for k, v in par.items() if isinstance(v, (int, float, bool)) and not k.startswith('oracle_')}
+        keep = ('vectors_checked', 'residual_err_in_tolerance_units', 'jacobian_err_in_tolerance_units', 'gpu_norm_rel_err_vs_tight',
+                'scipy_norm_rel_err_vs_tight', 'gpu_within_1e-8_of_tight', 'worst_state_err_vs_tight_solution',
+                'worst_sens_err_vs_tight_solution', 'vectors_passed_by_arbitration', 'vectors_failed')
+        out['parity'] = {k: par[k] for k in keep if k in par}
     cb = c.get('cpu_baseline')
     if isinstance(cb, dict):
         out['cpu'] = _pick(cb, ('value', 'unit', 'cores', 'finished', 'seconds'))
