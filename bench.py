@@ -666,6 +666,34 @@ def main():
                            "steps_per_pass": total_steps_per_pass}, "build": dict(_CURRENT_STAMPS)})
         return
 
+    # ---- what a user's call runs: explicit_method='auto' picks the pair by tolerance and batch (DOP853 at these defaults); the same
+    # pass (gather + integrate + assemble) timed with it -- its steps are not comparable with DOPRI45's, its ms per pass is ----
+    product_default = None
+    if world == 1 and args.method == 'dopri45':
+        try:
+            pick = _lib.predict_explicit_pair(tol['rtol'], int(V), 1, 2)[0]
+            o2 = _lib.make_opts(pick, rtol=(0.1 if pick == 'dop853' else 1.0) * tol['rtol'], atol=tol['atol'])
+
+            def step2():
+                _lib.check(lib.sbm_jacobian_batch(pj, p(th), V, ctypes.byref(o2), p(out['sims']), p(out['res']), p(out['J']), None,
+                                                  p(out['sf']), None, p(out['norms']), None, p(out['status']), p(out['nsteps'])),
+                           'sbm_jacobian_batch')
+            step2()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step2()
+            torch.cuda.synchronize(dev)
+            product_default = {"integrator": pick, "ms_per_step": 1e3 * (time.perf_counter() - t2) / args.steps,
+                               "accepted_steps_per_pass": int(out['nsteps'].sum().item()),
+                               "failed_vectors": int((out['status'] != 0).sum().item()),
+                               "note": "the pass of the headline workload as OdeModel / Project run it by default "
+                                       "(explicit_method='auto'); `value` stays on DOPRI45, the pair BASELINE.json's metric names"}
+            step()      # (the buffers hold the DOPRI45 pass again for the parity check below)
+            torch.cuda.synchronize(dev)
+        except Exception as e:   # noqa: BLE001
+            product_default = {"error": repr(e)[:200]}
+
     # ---- SURVEY.md section 8(d)'s host-inclusive figure: P upload and download of the sampled rows / norms ----
     host_incl = None
     if world == 1:
@@ -743,6 +771,8 @@ def main():
         result["roofline_valu_issue"] = roofline_valu
     if host_incl:
         result["host_inclusive"] = host_incl
+    if product_default:
+        result["product_default"] = product_default
     if with_cpu:
         result["cpu_baseline"] = cpu_baseline(gm, theta)
         result["cpu_baseline_all_cores"] = cpu_all
