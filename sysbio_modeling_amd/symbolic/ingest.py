@@ -12,8 +12,17 @@ reference's own generator writes (symbolic/sympy_tools.py:100-111,185-195) is st
 
 That form is parsed here (``ast``, no execution of the function) into the symbolic equations the HIP emitters start
 from; the sensitivity system is then DERIVED, not read -- and checked numerically against the ``sens_model`` that
-was handed in, which also tells which parameters carry sensitivity columns.  Anything else in the body (loops,
-branches, calls other than elementary functions) is refused: there is no CPU fallback to hide behind.
+was handed in, which also tells which parameters carry sensitivity columns.
+
+A hand-written right-hand side may also use (round 4) what unrolls to that form at parse time:
+
+    for i in range(<static ints>): ...        loops with static bounds (nested ones too), unrolled
+    y[<int expr>], p[<int expr>], yout[<int expr>]   indices that are integer expressions of loop variables / integer names
+    if <comparison of static ints>: ... else: ...     branches decided at parse time (``if i == 0``)
+    x += <expr> (and -=, *=, /=)              accumulators
+
+Anything that depends on the DATA -- a branch on y or p, a while loop, a call other than an elementary function -- is
+still refused: there is no CPU fallback to hide behind, and a right-hand side that is not smooth has no sensitivities.
 """
 from __future__ import annotations
 
@@ -47,21 +56,76 @@ def _source_of(fn):
     return textwrap.dedent(src), fn
 
 
-def _index_of(node, array):
-    """i for ``array[i]`` with a literal non-negative integer i, else None."""
+def _static_int(node, ienv):
+    """Value of an integer expression of literals and the names in ``ienv`` (loop variables, integer constants),
+    or None if ``node`` is not one."""
+    if isinstance(node, ast.Constant):
+        return node.value if isinstance(node.value, int) and not isinstance(node.value, bool) else None
+    if isinstance(node, ast.Name):
+        return ienv.get(node.id)
+    if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+        v = _static_int(node.operand, ienv)
+        return None if v is None else (-v if isinstance(node.op, ast.USub) else v)
+    if isinstance(node, ast.BinOp):
+        a, b = _static_int(node.left, ienv), _static_int(node.right, ienv)
+        if a is None or b is None:
+            return None
+        if isinstance(node.op, ast.Add):
+            return a + b
+        if isinstance(node.op, ast.Sub):
+            return a - b
+        if isinstance(node.op, ast.Mult):
+            return a * b
+        if isinstance(node.op, ast.FloorDiv) and b != 0:
+            return a // b
+        if isinstance(node.op, ast.Mod) and b != 0:
+            return a % b
+    return None
+
+
+def _static_bool(node, ienv):
+    """Truth value of a condition over static integers (comparisons, and / or / not), or None."""
+    if isinstance(node, ast.Compare):
+        vals = [_static_int(n, ienv) for n in [node.left] + list(node.comparators)]
+        if any(v is None for v in vals):
+            return None
+        ops = {ast.Eq: lambda a, b: a == b, ast.NotEq: lambda a, b: a != b, ast.Lt: lambda a, b: a < b,
+               ast.LtE: lambda a, b: a <= b, ast.Gt: lambda a, b: a > b, ast.GtE: lambda a, b: a >= b}
+        out = True
+        for op, a, b in zip(node.ops, vals[:-1], vals[1:]):
+            if type(op) not in ops:
+                return None
+            out = out and ops[type(op)](a, b)
+        return out
+    if isinstance(node, ast.BoolOp):
+        vals = [_static_bool(v, ienv) for v in node.values]
+        if any(v is None for v in vals):
+            return None
+        return all(vals) if isinstance(node.op, ast.And) else any(vals)
+    if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.Not):
+        v = _static_bool(node.operand, ienv)
+        return None if v is None else (not v)
+    return None
+
+
+def _index_of(node, array, ienv=None):
+    """i for ``array[i]`` with a non-negative integer i -- a literal, or an integer expression of the names in
+    ``ienv`` -- else None."""
     if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Name) and node.value.id == array:
         sl = node.slice
         if isinstance(sl, ast.Index):       # python < 3.9
             sl = sl.value
-        if isinstance(sl, ast.Constant) and isinstance(sl.value, int) and sl.value >= 0:
-            return sl.value
+        v = _static_int(sl, ienv or {})
+        if v is not None and v >= 0:
+            return v
     return None
 
 
 class _ToSympy(ast.NodeVisitor):
-    def __init__(self, names, arrays):
+    def __init__(self, names, arrays, ienv=None):
         self.names = names          # local name -> sympy expression
         self.arrays = arrays        # (y symbols, p symbols)
+        self.ienv = ienv if ienv is not None else {}     # static integers: loop variables, integer constants
 
     def visit(self, node):
         m = getattr(self, 'visit_' + type(node).__name__, None)
@@ -77,6 +141,8 @@ class _ToSympy(ast.NodeVisitor):
         return sympy.Float(node.value)
 
     def visit_Name(self, node):
+        if node.id in self.ienv:
+            return sympy.Integer(self.ienv[node.id])
         if node.id in self.names:
             return self.names[node.id]
         if node.id == 't':
@@ -85,12 +151,13 @@ class _ToSympy(ast.NodeVisitor):
 
     def visit_Subscript(self, node):
         for arr, table in (('y', self.arrays[0]), ('p', self.arrays[1])):
-            i = _index_of(node, arr)
+            i = _index_of(node, arr, self.ienv)
             if i is not None:
                 if i >= len(table):
                     raise IngestError("%s[%d] is out of range" % (arr, i))
                 return table[i]
-        raise IngestError("only y[<int>] and p[<int>] may be indexed")
+        raise IngestError("only y[<int>] and p[<int>] may be indexed (the index: a non-negative integer expression of "
+                          "literals and loop variables)")
 
     def visit_UnaryOp(self, node):
         v = self.visit(node.operand)
@@ -147,25 +214,86 @@ def parse_rhs(fn, n_y, n_p):
         def visit_Name(self, node):
             return ast.copy_location(ast.Name(id=rename.get(node.id, node.id), ctx=node.ctx), node)
     eqs = {}
-    for stmt in fdef.body:
-        if isinstance(stmt, ast.Expr) and isinstance(stmt.value, ast.Constant):
-            continue                                  # docstring
-        if isinstance(stmt, ast.Pass):
-            continue
-        if isinstance(stmt, ast.Return) and stmt.value is None:
-            continue
-        if not isinstance(stmt, ast.Assign) or len(stmt.targets) != 1:
-            raise IngestError("only assignments are understood in a right-hand side (line %d of %s)"
-                              % (stmt.lineno, fdef.name))
-        tgt = stmt.targets[0]
-        value = conv.visit(_Ren().visit(stmt.value))
-        i = _index_of(tgt, out_name)
-        if i is not None:
-            eqs[i] = value
-        elif isinstance(tgt, ast.Name):
-            names[tgt.id] = value
-        else:
-            raise IngestError("unsupported assignment target (line %d of %s)" % (stmt.lineno, fdef.name))
+    ienv = conv.ienv
+    budget = [200000]          # statements executed while unrolling (a typo in a range() must not hang the parser)
+
+    def run(stmts):
+        for stmt in stmts:
+            budget[0] -= 1
+            if budget[0] < 0:
+                raise IngestError("%s unrolls to more than 200000 statements" % fdef.name)
+            if isinstance(stmt, ast.Expr) and isinstance(stmt.value, ast.Constant):
+                continue                                  # docstring
+            if isinstance(stmt, ast.Pass):
+                continue
+            if isinstance(stmt, ast.Return) and stmt.value is None:
+                continue
+            if isinstance(stmt, ast.For):
+                # for <name> in range(<static ints>): unrolled
+                it = stmt.iter
+                if not (isinstance(stmt.target, ast.Name) and isinstance(it, ast.Call) and isinstance(it.func, ast.Name)
+                        and it.func.id == 'range' and 1 <= len(it.args) <= 3 and not it.keywords and not stmt.orelse):
+                    raise IngestError("only `for <name> in range(<static integers>)` loops are understood (line %d of %s)"
+                                      % (stmt.lineno, fdef.name))
+                bounds = [_static_int(_Ren().visit(a_), ienv) for a_ in it.args]
+                if any(b is None for b in bounds):
+                    raise IngestError("the bounds of a loop must be integers known when the function is read -- literals, "
+                                      "integer names, outer loop variables (line %d of %s)" % (stmt.lineno, fdef.name))
+                saved = ienv.get(stmt.target.id)
+                for v in range(*bounds):
+                    ienv[stmt.target.id] = v
+                    run(stmt.body)
+                if saved is None:
+                    ienv.pop(stmt.target.id, None)
+                else:
+                    ienv[stmt.target.id] = saved
+                continue
+            if isinstance(stmt, ast.If):
+                cond = _static_bool(_Ren().visit(stmt.test), ienv)
+                if cond is None:
+                    raise IngestError("a branch must be decided by loop variables / integer constants (`if i == 0:`); one that "
+                                      "depends on y, p or t has no place in a differentiable right-hand side (line %d of %s)"
+                                      % (stmt.lineno, fdef.name))
+                run(stmt.body if cond else stmt.orelse)
+                continue
+            if isinstance(stmt, ast.AugAssign):
+                ops = {ast.Add: lambda a_, b_: a_ + b_, ast.Sub: lambda a_, b_: a_ - b_, ast.Mult: lambda a_, b_: a_ * b_,
+                       ast.Div: lambda a_, b_: a_ / b_}
+                if type(stmt.op) not in ops:
+                    raise IngestError("unsupported augmented assignment (line %d of %s)" % (stmt.lineno, fdef.name))
+                value = conv.visit(_Ren().visit(stmt.value))
+                tgt = stmt.target
+                i = _index_of(tgt, out_name, ienv)
+                if i is not None:
+                    if i not in eqs:
+                        raise IngestError("%s[%d] is updated before it is assigned (line %d of %s)" % (out_name, i, stmt.lineno, fdef.name))
+                    eqs[i] = ops[type(stmt.op)](eqs[i], value)
+                elif isinstance(tgt, ast.Name) and tgt.id in names:
+                    names[tgt.id] = ops[type(stmt.op)](names[tgt.id], value)
+                else:
+                    raise IngestError("unsupported augmented assignment target (line %d of %s)" % (stmt.lineno, fdef.name))
+                continue
+            if not isinstance(stmt, ast.Assign) or len(stmt.targets) != 1:
+                raise IngestError("only assignments, static loops and static branches are understood in a right-hand side "
+                                  "(line %d of %s)" % (stmt.lineno, fdef.name))
+            tgt = stmt.targets[0]
+            # an integer constant (n = 20) may bound a loop or index an array later on
+            if isinstance(tgt, ast.Name):
+                iv = _static_int(_Ren().visit(stmt.value), ienv)
+                if iv is not None:
+                    ienv[tgt.id] = iv
+                    names.pop(tgt.id, None)
+                    continue
+            value = conv.visit(_Ren().visit(stmt.value))
+            i = _index_of(tgt, out_name, ienv)
+            if i is not None:
+                eqs[i] = value
+            elif isinstance(tgt, ast.Name):
+                names[tgt.id] = value
+                ienv.pop(tgt.id, None)
+            else:
+                raise IngestError("unsupported assignment target (line %d of %s)" % (stmt.lineno, fdef.name))
+    run(fdef.body)
     return eqs, ys, ps, src
 
 

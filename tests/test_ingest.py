@@ -57,18 +57,82 @@ def test_a_sens_model_that_disagrees_is_refused():
 
 
 def test_what_cannot_be_read_is_refused():
-    def loops(y, t, yout, p):
-        for i in range(2):
+    def data_loop(y, t, yout, p):
+        i = 0
+        while y[i] > 0:                       # (a loop whose trip count depends on the data)
             yout[i] = (-p[0] * y[i])
+            i += 1
+
+    def data_bound(y, t, yout, p):
+        for i in range(len(y)):               # (not a static integer)
+            yout[i] = (-p[0] * y[i])
+
+    def data_branch(y, t, yout, p):
+        if y[0] > 1.0:                        # (a right-hand side with a kink has no sensitivities)
+            yout[0] = -p[0]
+        else:
+            yout[0] = (-p[0] * y[0])
+        yout[1] = 0.0 * y[1]
 
     def unknown_call(y, t, yout, p):
         yout[0] = (np.interp(t, [0, 1], [0, 1]) - p[0] * y[0])
 
     def missing_row(y, t, yout, p):
         yout[1] = (-p[0] * y[0])
-    for fn in (loops, unknown_call, missing_row, lambda y, t, yout, p: None, np.sin):
+    for fn in (data_loop, data_bound, data_branch, unknown_call, missing_row, lambda y, t, yout, p: None, np.sin):
         with pytest.raises(TypeError):
             ingest.spec_from_callables(fn, None, 2, ['k'])
+
+
+def test_static_loops_and_branches_unroll_to_the_straight_line_form():
+    """The reference takes any callable (model/ode_model.py:27-44); a hand-written cascade is a loop over the species with
+    the first one special-cased.  Loops with static bounds, branches on loop variables, integer index expressions and
+    accumulators are unrolled at parse time (round 4) into exactly the equations of the straight-line form."""
+    n = 6
+
+    def looped(y, t, yout, p):
+        n = 6
+        total = 0.0
+        for i in range(n):
+            total += y[i]
+        for i in range(0, n):
+            if i == 0:
+                yout[i] = (p[0] / (1.0 + y[n - 1]) - p[n] * y[0])          # feedback from the last species
+            else:
+                yout[i] = (p[i] * y[i - 1] / (1.0 + y[i - 1]) - p[n + i] * y[i])
+        for i in range(1, n, 2):
+            yout[i] -= 0.01 * total * y[i]                                   # (odd species leak in proportion to the total)
+
+    def straight(y, t, yout, p):
+        total = y[0] + y[1] + y[2] + y[3] + y[4] + y[5]
+        yout[0] = (p[0] / (1.0 + y[5]) - p[6] * y[0])
+        yout[1] = (p[1] * y[0] / (1.0 + y[0]) - p[7] * y[1] - 0.01 * total * y[1])
+        yout[2] = (p[2] * y[1] / (1.0 + y[1]) - p[8] * y[2])
+        yout[3] = (p[3] * y[2] / (1.0 + y[2]) - p[9] * y[3] - 0.01 * total * y[3])
+        yout[4] = (p[4] * y[3] / (1.0 + y[3]) - p[10] * y[4])
+        yout[5] = (p[5] * y[4] / (1.0 + y[4]) - p[11] * y[5] - 0.01 * total * y[5])
+    names = ['k%d' % i for i in range(n)] + ['d%d' % i for i in range(n)]
+    a = ingest.spec_from_callables(looped, None, n, names)
+    b = ingest.spec_from_callables(straight, None, n, names)
+    for v in a.variables:
+        assert sympy.simplify(a.equations[v] - b.equations[v]) == 0
+    # ... and they ARE the function: the parsed equations reproduce a call of the Python callable
+    rng = np.random.default_rng(5)
+    yv, pv = rng.uniform(0.2, 1.5, n), rng.uniform(0.2, 1.5, 2 * n)
+    out = np.zeros(n)
+    looped(yv, 0.0, out, pv)
+    at = {sympy.Symbol('y%d' % i): yv[i] for i in range(n)}
+    at.update({sympy.Symbol(nm): pv[i] for i, nm in enumerate(names)})
+    assert np.allclose([float(a.equations[v].subs(at)) for v in a.variables], out, rtol=1e-13)
+    # nested loops and an index expression of two loop variables
+    def nested(y, t, yout, p):
+        for i in range(2):
+            yout[i] = 0.0 * y[i]
+            for j in range(2):
+                yout[i] += p[2 * i + j] * y[j]
+    c = ingest.spec_from_callables(nested, None, 2, ['a', 'b', 'c', 'd'])
+    ys = [sympy.Symbol('y0'), sympy.Symbol('y1')]
+    assert sympy.simplify(c.equations['y1'] - (sympy.Symbol('c') * ys[0] + sympy.Symbol('d') * ys[1])) == 0
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_UTILS), reason="the reference tree exists in the build container only")
@@ -115,3 +179,50 @@ def test_odemodel_from_plain_callables_on_the_gpu():
     Sr = odeint(wrap(pm.sens_model, 12), np.zeros(12), t, rtol=1e-10, atol=1e-10)[:, 3:]
     assert parity_err(m.simulate(p, t), Yr) <= 1.0
     assert parity_err(m.calc_jacobian(p, t, np.zeros(12)), Sr) <= 1.0
+
+
+@pytest.mark.gpu
+def test_a_hand_written_looped_cascade_runs_on_the_gpu():
+    """A right-hand side written the way a person writes a cascade -- a loop over the species, the first one special-cased --
+    goes through OdeModel (no sens_model handed in: the sensitivity system is derived) and agrees with odeint on the very
+    same callable, states and finite-difference-free sensitivities (odeint on the derived system of the oracle emitter)."""
+    from scipy.integrate import odeint
+    from sysbio_modeling_amd.model import OdeModel
+    from tests.conftest import parity_err
+    n = 8
+
+    def looped(y, t, yout, p):
+        n = 8
+        for i in range(n):
+            if i == 0:
+                yout[i] = (p[0] / (1.0 + y[n - 1]) - p[n] * y[0])
+            else:
+                yout[i] = (p[i] * y[i - 1] / (1.0 + y[i - 1]) - p[n + i] * y[i])
+    names = ['k%d' % i for i in range(n)] + ['d%d' % i for i in range(n)]
+    m = OdeModel(looped, None, n, names, model_name='looped cascade')
+    p = np.concatenate([np.full(n, 1.0), 0.1 * (1.0 + np.arange(n) / n)])
+    t = np.linspace(0, 60, 25)
+    out = np.zeros(n)
+
+    def f(y, tt):
+        looped(y, tt, out, p)
+        return out
+    Yr = odeint(f, np.zeros(n), t, rtol=1e-10, atol=1e-10)
+    assert parity_err(m.simulate(p, t), Yr) <= 1.0
+    # sensitivities: central differences of odeint at 1e-12 (the derived system itself is pinned by tests/test_symbolic.py)
+    S = m.calc_jacobian(p, t, np.zeros(n + n * 2 * n)).reshape(len(t), n, 2 * n)
+    for j in (0, 3, n + 2):
+        dp = 1e-6 * p[j]
+        pp, pm_ = p.copy(), p.copy()
+        pp[j] += dp
+        pm_[j] -= dp
+
+        def g(q):
+            o = np.zeros(n)
+
+            def ff(y, tt):
+                looped(y, tt, o, q)
+                return o
+            return odeint(ff, np.zeros(n), t, rtol=1e-12, atol=1e-14)
+        fd = (g(pp) - g(pm_)) / (2 * dp)
+        assert np.max(np.abs(S[:, :, j] - fd)) <= 1e-6 * max(1.0, np.max(np.abs(fd)))
