@@ -838,6 +838,60 @@ def run_dense(model, gm, dev, reps=3, cpu=True):
     return out
 
 
+def run_dense_stiff(model, gm, dev, reps=1, cpu=True):
+    """BASELINE configs[4] names a "dense Jacobian x S product on MFMA"; stiff50, the timed workload, has two non-zeros per
+    row.  This leg times a DENSE stiff network of the same size (models_zoo.dense_stiff_spec: 48 states, 1200 non-zeros of
+    df/dy, 48 sensitivity columns = 2352 ODEs, degradation rates over four decades) at the stiff integrator's default
+    options: sbm_iex_kernel with the row-distributed dense LU (IM_DIST) and per-column substitutions on the VALU -- there
+    are no MFMA tiles for the implicit path.  1024 vectors (the dense factorisation costs ~n^3 / 3 per
+    Newton matrix per trajectory); parity on the vectors the real reference was run on."""
+    import os
+    import torch
+    from sysbio_modeling_amd import _lib, models_zoo
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    from sysbio_modeling_amd.model import OdeModel
+    g5 = GeneratedModel(models_zoo.dense_stiff_spec())
+    m5 = OdeModel(g5.model, g5.sens_model, g5.n_vars, g5.param_order, model_name=g5.spec.name, use_jit=False)
+    m5.enable_jit(model.device_model.ctx)
+    V = 1024
+    _, Pn = models_zoo.dense_stiff_ensemble(V)
+    P = torch.from_numpy(Pn).to(dev)
+    t_np = np.concatenate([[0.0], np.linspace(0, models_zoo.DENSE_STIFF_T_END, 1000)[np.searchsorted(
+        np.linspace(0, models_zoo.DENSE_STIFF_T_END, 1000), models_zoo.DENSE_STIFF_MEASURE_TIMES)]])
+    t5 = torch.from_numpy(t_np).to(dev)
+    n, k = g5.n_vars, g5.n_sens
+    Y = torch.empty((V, len(t_np), n), dtype=torch.float64, device=dev)
+    S = torch.empty((V, len(t_np), n, k), dtype=torch.float64, device=dev)
+    st, ns, nr = (torch.empty((V,), dtype=torch.int32, device=dev) for _ in range(3))
+    o = dict(m5.integrator_options, method='implicit_extrap')
+    _lib.implicit_adaptive_defaults(o, ())
+    opts = _lib.make_opts('implicit_extrap', order=IEX_ORDER, rtol=o['rtol'], atol=o['atol'])
+    ms = _events(torch, dev, lambda: m5.device_model.sens_dev(P, t5, None, opts, Y, S, st, ns, nr), reps)
+    macro, rej = int(ns.sum().item()), int(nr.sum().item())
+    euler = (macro + rej) * (IEX_ORDER * (IEX_ORDER + 1) // 2)
+    out = {"workload": "dense stiff network dstiff48 (48 states, 1200 non-zeros of df/dy, 48 sensitivity columns: 2352 ODEs), "
+                       "%d vectors, 16 output times, SBM_IMPLICIT_EXTRAP order 8 at default tolerances, dense LU row-distributed "
+                       "over the lanes + per-column substitution on the VALU (no MFMA tiles on the implicit path)" % V,
+           "ms": ms, "vectors": V, "macro_steps_per_vector": macro / V, "rejected_macro_steps": rej, "euler_steps": euler,
+           "value": euler / (ms * 1e-3), "unit": "ODE-steps/s", "failed_vectors": int((st != 0).sum().item()),
+           "ms_per_1000_vectors": ms * 1000.0 / V}
+    gdir = os.path.join(B.REPO, 'tests', 'golden')
+    if os.path.exists(os.path.join(gdir, 'dstiff48_ref.npz')):
+        from oracle.tolerances import parity_err
+        g, gt = np.load(os.path.join(gdir, 'dstiff48_ref.npz')), np.load(os.path.join(gdir, 'dstiff48_tight.npz'))
+        nv = len(g['P'])
+        assert np.array_equal(Pn[:nv], g['P'])
+        Yg, Sg = Y[:nv, 1:].cpu().numpy(), S[:nv, 1:].cpu().numpy().reshape(nv, len(t_np) - 1, -1)
+        out["parity_of_timed_pass"] = {
+            "vectors_checked": nv,
+            "worst_state_err_vs_reference_in_tolerance_units": max(parity_err(Yg[v], g['Y'][v]) for v in range(nv)),
+            "worst_sens_err_vs_reference_in_tolerance_units": max(parity_err(Sg[v], g['S'][v]) for v in range(nv)),
+            "worst_state_err_vs_tight_solution": max(parity_err(Yg[v], gt['Y'][v]) for v in range(nv)),
+            "worst_sens_err_vs_tight_solution": max(parity_err(Sg[v], gt['S'][v]) for v in range(nv)),
+            "reference_vs_tight_sens": max(parity_err(g['S'][v], gt['S'][v]) for v in range(nv))}
+    return out
+
+
 def run_dop853(model, gm, dev, reps=3, cpu=True):
     """The headline ensemble (4096 vectors, 820 ODEs, 16 output times) through the DOP853 kernel alone, at OdeModel's
     default tolerances as the Python classes hand them to this method (rtol cut by ten): a profiling workload
@@ -861,5 +915,5 @@ def run_dop853(model, gm, dev, reps=3, cpu=True):
 
 
 RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'configs4_fixed': run_configs4_fixed,
-           'fit': run_fit, 'dense': run_dense, 'dop853': run_dop853}
+           'fit': run_fit, 'dense': run_dense, 'dop853': run_dop853, 'dense_stiff': run_dense_stiff}
 ORDER = ['configs1', 'configs3', 'configs4', 'fit', 'dense']

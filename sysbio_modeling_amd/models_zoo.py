@@ -131,6 +131,30 @@ def dense_spec(n=CASCADE_N, density=1.0, name=None, seed=11):
                      variables=[str(x) for x in xs], params=[str(k) for k in ks] + [str(d) for d in ds], equations=eq)
 
 
+def dense_stiff_spec(n=48, density=0.5, name=None):
+    """A DENSE stiff network (BASELINE configs[4] names a "dense Jacobian x S product"; stiff50 itself has two non-zeros per
+    row): the densely coupled model of ``dense_spec`` -- every species produced at a rate that saturates in a weighted sum
+    over ``density`` (n - 1) others -- with the degradation rates d_i FIXED (no sensitivity columns: n columns k_0 .. k_{n-1},
+    n (1 + n) coupled ODEs: 2352 at n = 48, the size of stiff50's system) and, in ``dense_stiff_ensemble``, spread over four
+    decades.  Its Newton matrix I - h J_y is dense: factored row-distributed over the lanes (emit_implicit.py IM_DIST)."""
+    base = dense_spec(n=n, density=density, name=name or 'dstiff%d' % n)
+    return ModelSpec(name=base.name, variables=base.variables, params=base.params, equations=base.equations,
+                     fixed=[p for p in base.params if p.startswith('d')])
+
+
+DENSE_STIFF_T_END = 2.0
+DENSE_STIFF_MEASURE_TIMES = np.linspace(0.125, 2.0, 16)
+
+
+def dense_stiff_ensemble(n_vectors=4096, n=48, seed=20261003, spread=0.25):
+    """(theta, P): production rates k_i = d_i x lognormal(spread), degradation rates d_i = 10^(4 i / (n - 1)) x lognormal(spread)
+    (time scales from 1 to 1e-4 against t_end = 2: stiff), parameters in model order (k_0.., d_0..)."""
+    rng = np.random.default_rng(seed)
+    d_nom = 10.0 ** np.linspace(0.0, 4.0, n)
+    theta = np.concatenate([np.log(d_nom), np.log(d_nom)])[None, :] + spread * rng.standard_normal((n_vectors, 2 * n))
+    return theta, np.exp(theta)
+
+
 CASCADE_T_END = 100.0
 CASCADE_MEASURE_TIMES = np.linspace(6.25, 100.0, 16)
 CASCADE_MEASURED_SPECIES = (4, 9, 14, 19)

@@ -744,3 +744,29 @@ def test_stiff_integrator_with_a_vanishing_atol(gpu_models):
         assert np.isfinite(S1).all() and np.isfinite(Y1).all()
         assert np.max(np.abs(Y1 - Y0) / (1e-6 * np.abs(Y0) + 1e-12)) <= 1.0, name
         assert np.max(np.abs(S1 - S0) / (1e-6 * np.maximum(np.abs(S0), 1e-6 * np.abs(S0).max()) + 1e-12)) <= 1.0, name
+
+
+@pytest.mark.gpu
+def test_dense_stiff_network_against_reference_golden(golden):
+    """A DENSE stiff network at the size of BASELINE configs[4] (models_zoo.dense_stiff_spec: 48 states, 1200 non-zeros of
+    df/dy, degradation rates over four decades, 48 sensitivity columns = 2352 ODEs) against the REAL reference OdeModel
+    (tests/golden/make_golden_dense_stiff.py), with LSODA at rtol 1e-12 by column groups as the tight solution.  The Newton
+    matrix is dense: factored row-distributed over the lanes, substituted per column on the VALU (there are no MFMA tiles for
+    the implicit path: DESIGN.md section 9).  Default options of the stiff integrator, one call."""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.model import OdeModel
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    g, gt = golden('dstiff48_ref.npz'), golden('dstiff48_tight.npz')
+    gm = GeneratedModel(models_zoo.dense_stiff_spec())
+    assert 'IM_DIST = true' in gm.hip_source and gm.n_vars == 48 and gm.n_sens == 48
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=gm.spec.name)
+    assert np.array_equal(models_zoo.dense_stiff_ensemble(4096)[1][:len(g['P'])], g['P'])
+    t_out = _from_zero(g['t'][g['idx']])
+    S, Y = m.calc_jacobian_batch(g['P'], t_out, return_states=True, method='implicit_controlled')
+    assert not m.last_info['status'].any()
+    for v in range(len(g['P'])):
+        ey = check_parity(Y[v, 1:], g['Y'][v], gt['Y'][v], what='dstiff48 vector %d, states' % v, criterion='parity')
+        es = check_parity(S[v, 1:], g['S'][v], gt['S'][v], what='dstiff48 vector %d, sensitivities' % v, criterion='parity')
+        print("dstiff48 vector %d: vs reference y %.2f S %.2f units%s; macro steps %d (+%d rejected)"
+              % (v, ey[0], es[0], '' if es[1] is None else ' (vs tight %.2f)' % es[1], m.last_info['n_steps'][v],
+                 m.last_info['n_rejected'][v]))

@@ -404,3 +404,21 @@ def test_scale_factor_grouping_equals_the_real_reference_base_class(golden):
             log_b = g['after_prior_update'][~data_rows][0]            # what the reference wrote into the prior row
             assert log_b == pytest.approx(np.log(g['sf'][0]), rel=1e-13)
             assert res[-1] == pytest.approx((log_b - g['prior'][0]) / g['prior'][1], rel=1e-12, abs=1e-14), c
+
+
+def test_dense_stiff_golden_is_the_oracles_call(golden):
+    """tests/golden/dstiff48_ref.npz (the REAL reference OdeModel on the dense stiff network, make_golden_dense_stiff.py):
+    the oracle's odeint call on the same generated C right-hand side gives the same numbers -- vector 0, ~12 s -- and the
+    tight solution by column groups agrees with it to LSODA's own accuracy."""
+    from sysbio_modeling_amd import models_zoo
+    from sysbio_modeling_amd.symbolic import GeneratedModel
+    g, gt = golden('dstiff48_ref.npz'), golden('dstiff48_tight.npz')
+    gm = GeneratedModel(models_zoo.dense_stiff_spec())
+    assert np.array_equal(models_zoo.dense_stiff_ensemble(4096)[1][:len(g['P'])], g['P'])
+    S = oo.calc_jacobian(gm, g['P'][0], g['t'], use_c=True)
+    Y = oo.simulate(gm, g['P'][0], g['t'], use_c=True)
+    # (the same call, but LSODA factors a dense 2352 x 2352 Jacobian with the BLAS of the day: the number of its threads moves
+    # the factors by rounding and the trajectory by ~1e-9 relative -- far inside the parity tolerance, not bit for bit)
+    from oracle.tolerances import parity_err
+    assert parity_err(Y[g['idx']], g['Y'][0]) <= 0.2 and parity_err(S[g['idx']], g['S'][0]) <= 0.2
+    assert parity_err(g['Y'][0], gt['Y'][0]) <= 3.0 and parity_err(g['S'][0], gt['S'][0]) <= 5.0
