@@ -483,7 +483,7 @@ def compact_line(full, full_path=None):
     line['build'] = full.get('build')
     line = _sig(line)
     # never longer than the limit: drop optional detail, least important first
-    for drop in (('configs', 'dense'), ('host_inclusive',), ('configs', 'fit'), ('configs', 'configs1'), ('build',),
+    for drop in (('configs', 'dense'), ('configs', 'dense_stiff'), ('host_inclusive',), ('configs', 'fit'), ('configs', 'configs1'), ('build',),
                  ('configs',), ('ranks', 'ms_per_step_by_rank'), ('product_default',)):
         if len(json.dumps(line, separators=(',', ':'))) + 1 <= LINE_LIMIT:
             break

@@ -916,4 +916,4 @@ def run_dop853(model, gm, dev, reps=3, cpu=True):
 
 RUNNERS = {'configs1': run_configs1, 'configs3': run_configs3, 'configs4': run_configs4, 'configs4_fixed': run_configs4_fixed,
            'fit': run_fit, 'dense': run_dense, 'dop853': run_dop853, 'dense_stiff': run_dense_stiff}
-ORDER = ['configs1', 'configs3', 'configs4', 'fit', 'dense']
+ORDER = ['configs1', 'configs3', 'configs4', 'fit', 'dense', 'dense_stiff']

@@ -89,11 +89,14 @@ def test_no_cpu_fallback_without_device(zoo):
 
 
 def test_odemodel_rejects_callables_it_cannot_compile():
-    """Only straight-line code in the reference's emitted form can be read from source (tests/test_ingest.py);
-    anything else is refused -- there is no SciPy path to fall back on."""
+    """Only code that unrolls to the reference's emitted straight-line form can be read from source (tests/test_ingest.py:
+    static loops and branches do since round 4); control flow that depends on the data is refused -- there is no SciPy
+    path to fall back on."""
     def f(y, t, yout, p):
-        for i in range(1):
+        i = 0
+        while y[i] > 0.0:
             yout[i] = -p[0] * y[i]
+            i += 1
     with pytest.raises(TypeError, match="no CPU fallback"):
         OdeModel(f, None, 1, ['k'], use_jit=False)
     with pytest.raises(TypeError, match="no CPU fallback"):

@@ -37,8 +37,10 @@ def test_ring_loop_of_the_rotated_kernel_has_no_other_vector_memory_access(tmp_p
     lds_loads = [i for i, ln in enumerate(body) if ln.startswith('global_load_lds_dwordx4')]
     # two sites (the prologue loop and the step loop), two loads each (RC by all lanes, A by lanes 0-31)
     assert len(lds_loads) == 4, lds_loads
-    waits = [i for i, ln in enumerate(body) if re.match(r's_waitcnt vmcnt\(8\)', ln)]
-    assert len(waits) == 1 and waits[0] > lds_loads[3], (waits, lds_loads)
+    # the hand-written wait: the first s_waitcnt vmcnt(8) behind the step loop's loads (the compiler may have one of its
+    # own elsewhere in the kernel)
+    waits = [i for i, ln in enumerate(body) if re.match(r's_waitcnt vmcnt\(8\)', ln) and i > lds_loads[3]]
+    assert waits and waits[0] - lds_loads[3] <= 12, (waits, lds_loads)
     # the step loop: from the first of its two loads to the backward branch that closes it -- everything the wavefront
     # executes between two visits of the wait.  Find the loop by its branch target: the nearest label before the loads.
     start = lds_loads[2]
