@@ -66,7 +66,7 @@ struct SbmIexShared {
   static constexpr int A_SIZE = A_SPARSE ? (M::NV * M::RL_MAXJP + 2) : (M::NV * 64 + 2);
   double Y[NROW];               // iterate, one component per row lane (rows lane, lane + 64, ...)
   double G[NROW];               // Newton residual
-  double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
+  double JY[sbm_ijy_size<M>()]; // J_y non-zeros by entry index (+ spare slot): the redundant factorisation's input only
   static constexpr int MF_SIZE = sbm_imf_size<M>(), RD_SIZE = sbm_ird_size<M>();
   __attribute__((aligned(16))) double MF[MF_SIZE];   // the factors (sbm_implicit_stepper.hpp)
   double RD[RD_SIZE];

@@ -60,6 +60,16 @@ template <class M>
 constexpr int sbm_imf_size() { return (M::IM_DIST ? M::NV * M::IM_LD : M::IM_MF) + 2; }
 template <class M>
 constexpr int sbm_ird_size() { return M::IM_DIST ? M::NV : 1; }
+// J_y by entry index: read by im_build only (neither triangular nor row-distributed) -- a dense model's 1200 entries are
+// 9.6 KB of LDS nobody reads otherwise
+template <class M>
+constexpr int sbm_ijy_size() {
+#ifdef SBM_IMPLICIT_REDUNDANT_LU
+  return M::NJY + 2;
+#else
+  return (M::IM_TRI || M::IM_DIST) ? 2 : M::NJY + 2;
+#endif
+}
 
 template <class M, class Sh>
 struct SbmImplicitStepper {
@@ -94,7 +104,7 @@ struct SbmImplicitStepper {
     chunk = chunk_;
     constexpr int NCH = (M::NK + 63) / 64;
     for (int i = lane; i < Sh::A_SIZE; i += 64) sh->A[i] = 0.0;
-    for (int i = lane; i < M::NJY + 2; i += 64) sh->JY[i] = 0.0;
+    for (int i = lane; i < sbm_ijy_size<M>(); i += 64) sh->JY[i] = 0.0;
     for (int i = lane; i < Sh::MF_SIZE; i += 64) sh->MF[i] = 0.0;
     for (int i = lane; i < Sh::RD_SIZE; i += 64) sh->RD[i] = 1.0;
 #pragma unroll

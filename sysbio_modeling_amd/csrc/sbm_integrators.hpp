@@ -1834,7 +1834,7 @@ struct SbmImidShared {
   static constexpr int A_SIZE = A_SPARSE ? (M::NV * M::RL_MAXJP + 2) : (M::NV * 64 + 2);
   double Y[NROW];               // iterate, one component per row lane (rows lane, lane + 64, ...)
   double G[NROW];               // Newton residual
-  double JY[M::NJY + 2];        // J_y non-zeros by entry index (+ spare slot)
+  double JY[sbm_ijy_size<M>()]; // J_y non-zeros by entry index (+ spare slot): the redundant factorisation's input only
   double A[A_SIZE];             // A[i][c] = J_p[i][c] (+ spare slot)
   static constexpr int MF_SIZE = sbm_imf_size<M>(), RD_SIZE = sbm_ird_size<M>();
   __attribute__((aligned(16))) double MF[MF_SIZE];   // the factors (IM_TRI: reciprocal pivots and scaled entries; IM_DIST: dense rows)

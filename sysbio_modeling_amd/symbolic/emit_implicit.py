@@ -58,11 +58,16 @@ def symbolic_lu(n, entries):
 
 
 def lds_leading_dimension(n):
-    """Row stride (in doubles) of the n x n factor table in LDS: >= n and = 2 mod 32, so that the 64 lanes' 16-byte
-    reads of their own rows (stride 2 * LD dwords) fall on different banks."""
+    """Row stride (in doubles) of the n x n factor table in LDS: the smallest LD >= n with LD / 2 ODD.  The lanes read their
+    own rows 16 bytes at a time (ds_read_b128: lane groups of 16 on banks (a / 4) mod 64): lane l's address is 2 LD l dwords,
+    i.e. slot (LD / 2) l mod 16 of the 256-byte bank row -- distinct for the 16 lanes of a group exactly when LD / 2 is odd.
+    (Round 3 rounded up to 2 mod 32 -- 66 for 48 states, 25 KB where 19 do: with the rest of the extrapolation kernel's
+    tables that was 55 KB of LDS per wavefront, two wavefronts per CU instead of four.)"""
     if n <= 2:
         return 2
-    ld = ((n - 2 + 31) // 32) * 32 + 2
+    ld = n + (n & 1)
+    if (ld // 2) % 2 == 0:
+        ld += 2
     return ld
 
 
