@@ -770,3 +770,30 @@ def test_dense_stiff_network_against_reference_golden(golden):
         print("dstiff48 vector %d: vs reference y %.2f S %.2f units%s; macro steps %d (+%d rejected)"
               % (v, ey[0], es[0], '' if es[1] is None else ' (vs tight %.2f)' % es[1], m.last_info['n_steps'][v],
                  m.last_info['n_rejected'][v]))
+
+
+@pytest.mark.gpu
+def test_stiff_chain_restarted_from_given_sensitivities(gpu_models, golden):
+    """A chain model normally integrates with its sensitivity columns held rotated (sbm_iex_seq_kernel<M, true>: rows above a
+    column's J_p entry are structurally zero).  Initial sensitivities handed in by the caller need not respect that
+    structure, so such a call runs the un-rotated variant of the kernel (generated column step with inverse-ballot picks).
+    Both on stiff50: 0 -> t2 in one call (rotated) against 0 -> t1, then t1 -> t2 from (y, S)(t1) (un-rotated) -- the same
+    solution within the integration tolerance, and within parity of the reference golden at t2."""
+    m = gpu_models('stiff50')
+    g = golden('stiff50_ref.npz')
+    P = g['P'][:2]
+    tg = g['t'][g['idx']]
+    t1, t2 = float(tg[5]), float(tg[-1])
+    kw = dict(method='implicit_controlled')
+    S2, Y2 = m.calc_jacobian_batch(P, np.array([0.0, t1, t2]), return_states=True, **kw)
+    assert not m.last_info['status'].any()
+    for v in range(2):
+        y0 = np.concatenate([Y2[v, 1], S2[v, 1].ravel()])
+        Sb, Yb = m.calc_jacobian_batch(P[v:v + 1], np.array([t1, t2]), init_conditions=y0, return_states=True, **kw)
+        assert not m.last_info['status'].any()
+        assert np.array_equal(Yb[0, 0], Y2[v, 1]) and np.array_equal(Sb[0, 0].ravel(), S2[v, 1].ravel())
+        ey = np.max(np.abs(Yb[0, 1] - Y2[v, 2]) / (1e-8 * np.abs(Y2[v, 2]) + 5e-9))
+        es = np.max(np.abs(Sb[0, 1] - S2[v, 2]) / (1e-8 * np.abs(S2[v, 2]) + 5e-9))
+        print("stiff50 vector %d restarted at t = %.3g: y %.2f S %.2f parity units from the one-call solution" % (v, t1, ey, es))
+        assert ey <= 1.0 and es <= 1.0
+        assert parity_err(Yb[0, 1], g['Y'][v][-1]) <= 1.5 and parity_err(Sb[0, 1].ravel(), g['S'][v][-1]) <= 2.5
