@@ -7,6 +7,7 @@ Two levels of parity:
     convergence of the raw scheme and agreement of the Richardson-extrapolated result.
 The model's sparse LU (emit_implicit.py) is exercised on three sparsity patterns: bidiagonal
 (stiff50), bidiagonal + corner with fill-in (cascade20) and a 2x2 block (Michaelis-Menten)."""
+import os
 import warnings
 
 import numpy as np
@@ -797,3 +798,56 @@ def test_stiff_chain_restarted_from_given_sensitivities(gpu_models, golden):
         print("stiff50 vector %d restarted at t = %.3g: y %.2f S %.2f parity units from the one-call solution" % (v, t1, ey, es))
         assert ey <= 1.0 and es <= 1.0
         assert parity_err(Yb[0, 1], g['Y'][v][-1]) <= 1.5 and parity_err(Sb[0, 1].ravel(), g['S'][v][-1]) <= 2.5
+
+
+_SEQ_VS_OLD = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from sysbio_modeling_amd import models_zoo
+from sysbio_modeling_amd.model import OdeModel
+from sysbio_modeling_amd.symbolic import GeneratedModel
+out = {}
+for n in (24, 34):
+    gm = GeneratedModel(models_zoo.stiff_spec(n, name='stiff%d_free' % n, fixed_deactivation=False))
+    m = OdeModel(gm.model, gm.sens_model, gm.n_vars, gm.param_order, model_name=gm.spec.name)
+    P = models_zoo.stiff_ensemble(4, n=n)[1][:3]
+    t = np.array([0.0, 1.0, 4.0, 10.0])
+    S, Y = m.calc_jacobian_batch(P, t, return_states=True, method='implicit_controlled')
+    out['Y%d' % n], out['S%d' % n] = Y, S
+    out['st%d' % n], out['ns%d' % n] = m.last_info['status'], m.last_info['n_steps']
+np.savez(sys.argv[2], **out)
+'''
+
+
+@pytest.mark.gpu
+def test_general_seq_kernel_equals_round3_kernel_with_two_entries_per_row_and_two_chunks(tmp_path):
+    """Chains whose rows have TWO J_p entries (rate a_i and deactivation strength b_i both free: 2 n sensitivity columns) do
+    not qualify for rotated columns: sbm_iex_seq_kernel<M, false> walks them with the generated column step (inverse-ballot
+    picks, RL_MAXJP = 2) -- with 24 states in one chunk of 48 columns, with 34 states in TWO chunks (68 columns: two
+    workgroups per trajectory, each redoing the state).  Same scheme as round 3's sbm_iex_kernel (SBM_IEX_SEQ=0, a second
+    process: the switch is read once): the two agree far inside the integration tolerance and take the same steps."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'seq_vs_old.py'
+    script.write_text(_SEQ_VS_OLD)
+    res = {}
+    for tag, env in (('seq', {}), ('old', {'SBM_IEX_SEQ': '0'})):
+        p = subprocess.run([sys.executable, str(script), repo, str(tmp_path / (tag + '.npz'))], env=dict(os.environ, **env),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tag] = np.load(tmp_path / (tag + '.npz'))
+    for n in (24, 34):
+        a, b = res['seq'], res['old']
+        assert not a['st%d' % n].any() and not b['st%d' % n].any()
+        assert np.max(np.abs(a['ns%d' % n].astype(int) - b['ns%d' % n].astype(int))) <= 2, (a['ns%d' % n], b['ns%d' % n])
+        ey = np.max(np.abs(a['Y%d' % n] - b['Y%d' % n]) / (1e-9 * np.abs(b['Y%d' % n]) + 3e-13))
+        Sb = b['S%d' % n]
+        es = np.max(np.abs(a['S%d' % n] - Sb) / (1e-9 * np.maximum(np.abs(Sb), 1e-6 * np.abs(Sb).max()) + 3e-13))
+        print("stiff%d_free (%d columns): seq vs round-3 kernel y %.3g S %.3g integration tolerances; macro steps %s / %s"
+              % (n, 2 * n, ey, es, a['ns%d' % n], b['ns%d' % n]))
+        # two runs of one scheme whose sums are associated differently (T_j against T_j - S_n): each within the integration
+        # tolerance of the solution, so within a few tolerances of each other -- and far inside the parity tolerance
+        assert ey <= 3.0 and es <= 3.0
+        assert parity_err(a['Y%d' % n], b['Y%d' % n]) <= 0.3 and parity_err(a['S%d' % n], Sb) <= 0.3
