@@ -108,3 +108,16 @@ def test_emit_writes_the_whole_buffer(tmp_path, monkeypatch):
     bench.emit(obj)
     monkeypatch.setattr(os, 'write', real_write)
     assert json.loads(b''.join(chunks).decode()) == obj and len(chunks) > 10
+
+
+def test_round4_record_and_its_committed_line_agree():
+    """profiles/r04/bench_full.json (the full record of the round's last run) -> the line; the committed line is that."""
+    with open(os.path.join(REPO, 'profiles', 'r04', 'bench_full.json')) as fh:
+        full = json.load(fh)
+    back = _check(bench.compact_line(full, 'gpurun_out/bench_full.json'), full)
+    with open(os.path.join(REPO, 'profiles', 'r04', 'bench.json')) as fh:
+        committed = json.loads(fh.read())
+    assert committed['value'] == back['value'] and committed['roofline'] == back['roofline']
+    assert back['roofline']['traffic'] is not None and back['cpu_baseline']['parity_of_timed_pass']['gpu_within_1e-8_of_tight'] is True
+    assert back['configs']['configs4']['roofline']['bound'] == 'instruction_issue'
+    assert back['product_default']['integrator'] in ('dop853', 'dopri45')
