@@ -99,9 +99,13 @@ def jacobians_from(gm, use_c=True):
 
 
 def integrate(gm, p, t_out, rtol=3e-9, atol=3e-12, order=0, t0=0.0, y0=None, s0=None, with_sens=True, h0=0.0,
-              max_steps=200000, use_c=True, predictor=None):
+              max_steps=200000, use_c=True, predictor=None, sums='differences'):
     """Returns (Y (len(t_out), n), S (len(t_out), n*k) or None, info) with info = dict(n_steps, n_reject, n_eval,
     n_euler, status); status as the kernel's: 0 ok, 1 max_steps, 3 step_underflow.
+
+    ``sums``: how the extrapolations of the sensitivities are accumulated -- 'differences' (sum_j w_j (T_j - S_n), added to
+    S_n: csrc/sbm_implicit_extrap.hpp::sbm_iex_kernel) or 'values' (sum_j w_j T_j, which IS T_KK since the weights add up to
+    one: csrc/sbm_implicit_extrap_seq.hpp, round 4).  The same numbers up to the rounding of the sums.
 
     ``predictor`` (experiments only, tests/tools/dev_iex_predictor.py; the kernel has no such thing): callable
     (j, m, h, Hs, y_n, ya, default, previous_sequence_states) -> Newton's starting point of step m of sequence j, in place
@@ -200,15 +204,19 @@ def integrate(gm, p, t_out, rtol=3e-9, atol=3e-12, order=0, t0=0.0, y0=None, s0=
                 yh += wh[j] * (ya - y)
                 ye += we[j] * (ya - y)
                 if with_sens:
-                    zh += wh[j] * (Sj - S)
-                    ze += we[j] * (Sj - S)
+                    if sums == 'values':
+                        zh += wh[j] * Sj
+                        ze += we[j] * Sj
+                    else:
+                        zh += wh[j] * (Sj - S)
+                        ze += we[j] * (Sj - S)
             err = np.inf
             colmax_new = colmax
             if ok:
                 with np.errstate(all='ignore'):
                     cs = 0.0
                     if with_sens and k:
-                        Tk = S + zh
+                        Tk = zh if sums == 'values' else S + zh
                         colmax_new = np.maximum(colmax, np.max(np.abs(Tk), axis=0))
                         r = ze / (rtol * np.maximum(np.abs(Tk), FLOOR * colmax_new[None, :]) + atol)
                         cs = np.max(np.sum(r * r, axis=0))
@@ -221,7 +229,7 @@ def integrate(gm, p, t_out, rtol=3e-9, atol=3e-12, order=0, t0=0.0, y0=None, s0=
                 ydot = yh / Hs
                 y = y + yh
                 if with_sens:
-                    S = S + zh
+                    S = zh.copy() if sums == 'values' else S + zh
                 colmax = colmax_new
                 t = target if landing else t + Hs
                 info['n_steps'] += 1

@@ -162,3 +162,19 @@ def test_wide_stiff_golden_is_the_oracles_call_and_column_groups_give_the_tight_
     t = np.concatenate([[0.0], g['t'][g['idx']][:6]])
     Yc, Sc = oo.tight_stiff_solution_by_columns(gm, g['P'][1], t, group=25)
     assert parity_err(Yc[1:], gt['Y'][1][:6]) < 1e-2 and parity_err(Sc[1:], gt['S'][1][:6]) < 1e-2
+
+
+def test_iex_sums_of_values_and_of_differences_are_the_same_scheme(zoo, golden):
+    """The two accumulations of the extrapolated sensitivities -- sum_j w_j (T_j - S_n) added to S_n (sbm_iex_kernel) and
+    sum_j w_j T_j (sbm_iex_seq_kernel: the weights add up to one) -- are one scheme: on a stiff golden vector the same steps
+    and the same rows up to the rounding of the sums (3e3 eps relative to |S| per macro step)."""
+    from oracle import iex_oracle
+    g = golden('stiff50_ref.npz')
+    gm = zoo('stiff50')
+    t = g['t'][g['idx']][:3]
+    kw = dict(rtol=3e-8, atol=3e-11, order=6)
+    Ya, Sa, ia = iex_oracle.integrate(gm, g['P'][0], t, sums='differences', **kw)
+    Yb, Sb, ib = iex_oracle.integrate(gm, g['P'][0], t, sums='values', **kw)
+    assert ia['status'] == 0 and ib['status'] == 0 and abs(ia['n_steps'] - ib['n_steps']) <= 1 and ia['n_reject'] == ib['n_reject']
+    assert np.max(np.abs(Ya - Yb) / (3e-8 * np.abs(Ya) + 3e-11)) <= 0.05
+    assert np.max(np.abs(Sa - Sb) / (3e-8 * np.maximum(np.abs(Sa), 1e-6 * np.abs(Sa).max(axis=0)) + 3e-11)) <= 0.05
